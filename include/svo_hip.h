@@ -1,0 +1,140 @@
+/*
+ * svo_hip.h -- the drop-in boundary: a C ABI over the MI355X (gfx950) HIP implementation of
+ * ria8651/octree-tracer's GPU path.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * What each entry point replaces in the reference (file:line under /root/reference/src):
+ *   svo_ctx_create / destroy      Gpu::new (gpu.rs:11-49): instance/adapter/device/queue
+ *   svo_nodes_alloc               Render::new node buffer, `octree.expanded(10_000_000)`
+ *                                 create_buffer_init STORAGE|COPY_DST (render.rs:53-61)
+ *   svo_nodes_write               queue.write_buffer(&render.node_buffer, 0, nodes)
+ *                                 (app.rs:113-118, :163-168, :194-199, :239-244)
+ *   svo_set_uniforms              Render::update -> queue.write_buffer(uniform_buffer)
+ *                                 (render.rs:191-212); struct Uniforms (render.rs:287-322,
+ *                                 shader.wgsl:2-13)
+ *   svo_render / svo_render_tiles Render::render: one pass, draw(0..4, 0..1) running fs_main once
+ *                                 per pixel (render.rs:217-284, shader.wgsl:250-305)
+ *   svo_trace_rays                octree_ray on caller-supplied rays (shader.wgsl:191-248; the
+ *                                 shadow ray of shader.wgsl:276 is such a ray)
+ *   svo_scan_dispatch             Compute::update: dispatch(ceil(n/16/256), 256, 1) of
+ *                                 compute.wgsl main (compute.rs:99-127, compute.wgsl:26-47)
+ *   svo_scan_read                 map_async + device.poll(Wait) + counter reset
+ *                                 (adaptive.rs:12-23, :76-87)
+ *   svo_sync                      device.poll(Maintain::Wait)
+ * Errors: the reference unwraps/panics (gpu.rs:24,39; adaptive.rs:66,124); here every call
+ * returns 0 on success or a negative svo_status, and svo_last_error() gives the text.
+ * Threading: like the reference (all device calls from one thread, main.rs:40-88) a ctx is not
+ * thread-safe; one ctx per GPU, each ctx launches on one HIP stream.
+ */
+#ifndef SVO_HIP_H
+#define SVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVO_VOXEL_OFFSET 134217728u /* octree.rs:5, shader.wgsl:30 */
+
+typedef enum svo_status {
+    SVO_OK = 0,
+    SVO_ERR_ARG = -1,     /* bad argument */
+    SVO_ERR_HIP = -2,     /* a HIP runtime call failed; see svo_last_error */
+    SVO_ERR_STATE = -3,   /* call order (e.g. render before nodes_alloc) */
+    SVO_ERR_NO_DEVICE = -4
+} svo_status;
+
+/* Uniform flags: the reference's five 1-byte bools (render.rs:294-299) as explicit bits. */
+#define SVO_F_PAUSE_ADAPTIVE 1u
+#define SVO_F_SHOW_STEPS 2u
+#define SVO_F_SHOW_HITS 4u
+#define SVO_F_SHADOWS 8u
+#define SVO_F_MISC_BOOL 16u
+
+typedef struct svo_uniforms {
+    float camera[16];         /* column-major */
+    float camera_inverse[16]; /* column-major */
+    float dimensions[4];      /* (W, H, 0, 0) */
+    float sun_dir[4];
+    uint32_t flags;
+    float misc_value;
+} svo_uniforms;
+
+/* HitInfo (shader.wgsl:182-189) as a 16-byte record.
+ * steps_depth_hit: bits 0..7 steps, 8..15 depth, bit 16 hit, bits 17..22 normal code;
+ * packed_normal: 2 bits per axis (x: bits 0..1, y: 2..3, z: 4..5), 0 -> 0, 1 -> +1, 2 -> -1.
+ * voxel_index is HitInfo.value: the node-array index of the leaf word, or the reference's
+ * sentinels 0 (never entered the cube), 0x20202000 (left the cube), 0xFF000000 (>100 steps).
+ * t = ray_box_dist entry distance + t_current of the last DDA step. */
+typedef struct svo_hit {
+    uint32_t voxel_index;
+    float t;
+    uint32_t steps_depth_hit;
+    uint32_t packed_normal;
+} svo_hit;
+
+typedef struct svo_ctx svo_ctx;
+
+/* kernel variants (svo_set_option SVO_OPT_VARIANT) */
+#define SVO_VARIANT_RESTART 0 /* reference-shaped: float-compare descent from the root every step */
+#define SVO_VARIANT_STACK 1   /* integer path codes + per-ray ancestor stack in LDS + LDS top table + refill */
+
+typedef enum svo_option {
+    SVO_OPT_VARIANT = 0,
+    SVO_OPT_TIMING = 1,      /* 1: bracket every trace launch with HIP events on the ctx stream */
+    SVO_OPT_GRID_BLOCKS = 2, /* persistent grid size override (0 = auto) */
+    SVO_OPT_REFILL_MIN = 3,  /* idle lanes needed before a wave refills */
+    SVO_OPT_STRIP_ITEMS = 4, /* pixel slots a wave claims at a time (multiple of 64) */
+    SVO_OPT_DYNAMIC_STRIPS = 5 /* 1: waves claim strips from a device counter; 0: static round-robin */
+} svo_option;
+
+int svo_ctx_create(int hip_device, svo_ctx **out);
+int svo_ctx_destroy(svo_ctx *ctx);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the ctx's own. */
+int svo_ctx_set_stream(svo_ctx *ctx, void *hip_stream);
+int svo_set_option(svo_ctx *ctx, int option, int64_t value);
+const char *svo_last_error(const svo_ctx *ctx);
+int svo_sync(svo_ctx *ctx);
+
+int svo_nodes_alloc(svo_ctx *ctx, size_t capacity_words);
+/* Use caller-owned device memory as the node buffer instead (no copy). */
+int svo_nodes_bind_device(svo_ctx *ctx, uint32_t *device_words, size_t capacity_words);
+int svo_nodes_write(svo_ctx *ctx, size_t word_offset, const uint32_t *host_words, size_t n);
+int svo_nodes_read(svo_ctx *ctx, size_t word_offset, uint32_t *host_words, size_t n);
+/* Device pointer of the node buffer (for zero-copy consumers). */
+int svo_nodes_device_ptr(svo_ctx *ctx, uint32_t **out, size_t *capacity_words);
+
+int svo_set_uniforms(svo_ctx *ctx, const svo_uniforms *u);
+
+/* Trace the primary rays of the pixel rectangle [x0,x0+tile_w) x [y0,y0+tile_h) of a
+ * width x height frame (must equal uniforms.dimensions).  hits_out (tile_w*tile_h records,
+ * row-major within the rectangle) and rgba_out (tile_w*tile_h RGBA8, optional, the shaded colour
+ * of fs_main) are DEVICE pointers; either may be NULL.  Asynchronous on the ctx stream. */
+int svo_render(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0,
+               uint32_t tile_w, uint32_t tile_h, svo_hit *hits_out, uint32_t *rgba_out);
+/* Same with HOST output pointers; blocking (staging buffer + D2H). */
+int svo_render_host(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0,
+                    uint32_t tile_w, uint32_t tile_h, svo_hit *hits_out, uint32_t *rgba_out);
+/* Multi-GPU sharding: the frame is cut into tile_w x tile_h tiles numbered row-major; this call
+ * traces tiles first_tile, first_tile + tile_stride, ... and writes them contiguously in that
+ * order (tile k of this rank at hits_out[k * tile_w * tile_h], row-major inside the tile).
+ * width and height must be multiples of the tile size. */
+int svo_render_tiles(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t tile_w,
+                     uint32_t tile_h, uint32_t first_tile, uint32_t tile_stride,
+                     svo_hit *hits_out, uint32_t *rgba_out);
+/* octree_ray over n explicit rays (6 floats each: pos.xyz, dir.xyz; device pointers). */
+int svo_trace_rays(svo_ctx *ctx, const float *rays, size_t n_rays, svo_hit *hits_out);
+
+/* Duration of the most recent trace launch in ms (needs SVO_OPT_TIMING=1); blocks on it. */
+int svo_last_render_ms(svo_ctx *ctx, float *ms);
+
+/* Counter scan (compute.wgsl).  Lists hold `capacity` words: slot 0 = count, slots 1.. = indices. */
+int svo_scan_dispatch(svo_ctx *ctx, uint32_t node_length);
+int svo_scan_read(svo_ctx *ctx, uint32_t *sub, uint32_t *n_sub, uint32_t *unsub, uint32_t *n_unsub,
+                  size_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

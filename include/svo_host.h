@@ -1,0 +1,112 @@
+/*
+ * svo_host.h -- host-side data model of the drop-in: the octree containers the reference keeps
+ * on the CPU and feeds to the node buffer, plus camera maths and deterministic scene generators.
+ * C ABI (the C++ classes behind it live in octree-tracer_amd/csrc/svo_host.cpp).
+ *
+ * Reference counterparts (file:line under /root/reference/src):
+ *   svo_cpu_octree_*      CpuOctree (cpu_octree.rs:17-273): new/add_voxels :23-45, find_voxel
+ *                         :48-76, put_in_voxel :100-111, load_file :113-125, .rsvo :128-175,
+ *                         .vox :177-210, to_octree :233-252; World::generate_mip_tree
+ *                         (world.rs:234-336)
+ *   svo_octree_*          Octree (octree.rs:43-162): new :51-66, subdivide :72-93, unsubdivide
+ *                         :95-110, find_voxel :113-141, expanded :143-148, pos_offset :154-161
+ *   svo_camera_matrices   Render::update (render.rs:191-206) + create_proj_matrix (main.rs:139-162)
+ *   svo_gen_*             no counterpart: the reference's generator (procedual.wgsl) is racy and
+ *                         nondeterministic; these are deterministic CPU scene builders for the
+ *                         benchmark configs.
+ */
+#ifndef SVO_HOST_H
+#define SVO_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVO_CHUNK_OFFSET 2147483648u /* cpu_octree.rs:3 */
+
+typedef struct svo_cpu_octree svo_cpu_octree;
+typedef struct svo_octree svo_octree;
+
+/* ---- CpuOctree ---- */
+svo_cpu_octree *svo_cpu_octree_new(uint8_t mask);
+void svo_cpu_octree_free(svo_cpu_octree *t);
+size_t svo_cpu_octree_len(const svo_cpu_octree *t);
+/* load_file: dispatch on the extension ("rsvo" | "vox"), else "Unknown file type". NULL on error. */
+svo_cpu_octree *svo_cpu_octree_load_file(const char *path, uint32_t octree_depth, char *err, size_t errlen);
+svo_cpu_octree *svo_cpu_octree_load_vox(const uint8_t *data, size_t len, char *err, size_t errlen);
+svo_cpu_octree *svo_cpu_octree_load_rsvo(const uint8_t *data, size_t len, uint32_t octree_depth, char *err,
+                                         size_t errlen);
+/* voxel list in file order (x, y, z, file colour index), palette = 256 LE RGBA words */
+svo_cpu_octree *svo_cpu_octree_from_voxels(uint32_t size, const uint8_t *xyzi, size_t n_voxels,
+                                           const uint32_t *palette256, char *err, size_t errlen);
+void svo_cpu_octree_put_in_voxel(svo_cpu_octree *t, const float pos[3], const uint8_t rgb[3], uint32_t depth);
+void svo_cpu_octree_put_in_block(svo_cpu_octree *t, const float pos[3], uint32_t block_id, uint32_t depth);
+/* max_depth < 0: None */
+void svo_cpu_octree_find_voxel(const svo_cpu_octree *t, const float pos[3], int64_t max_depth, uint64_t *index,
+                               uint32_t *depth, float node_pos[3]);
+void svo_cpu_octree_get_node_mask(const svo_cpu_octree *t, size_t node, uint8_t rgb_out[24]);
+/* GPU words (to_octree); out holds svo_cpu_octree_len words */
+void svo_cpu_octree_to_octree(const svo_cpu_octree *t, uint32_t *out);
+void svo_cpu_octree_raw(const svo_cpu_octree *t, uint32_t *pointers, uint8_t *rgb);
+void svo_cpu_octree_generate_mips(svo_cpu_octree *t, uint8_t top_mip[3]);
+/* parse a .vox: returns voxel count (or -1), size[3]; xyzi/palette optional */
+int64_t svo_vox_parse(const uint8_t *data, size_t len, uint32_t size[3], uint8_t *xyzi, size_t xyzi_cap,
+                      uint32_t *palette256, char *err, size_t errlen);
+/* write a minimal .vox (SIZE, XYZI, RGBA); returns bytes needed/written */
+size_t svo_vox_write(uint32_t size, const uint8_t *xyzi, size_t n_voxels, const uint32_t *palette256, uint8_t *out,
+                     size_t cap);
+/* serialise a CpuOctree as an .rsvo child-mask stream (inverse of load_rsvo); returns bytes */
+size_t svo_rsvo_write(const svo_cpu_octree *t, uint8_t *out, size_t cap);
+
+/* ---- Octree (host mirror of the device node array) ---- */
+svo_octree *svo_octree_new(const uint8_t mask_rgb[24]);
+svo_octree *svo_octree_from_words(const uint32_t *words, size_t n);
+void svo_octree_free(svo_octree *o);
+size_t svo_octree_len(const svo_octree *o);
+const uint32_t *svo_octree_raw_data(const svo_octree *o);
+uint32_t svo_octree_get_node(const svo_octree *o, size_t index);
+/* 0 ok; -1 "Node already subdivided!" (the reference panics) */
+int svo_octree_subdivide(svo_octree *o, size_t node, const uint8_t mask_rgb[24], uint32_t depth);
+/* 0 ok; 1 node was not subdivided (reference prints and returns); -1 no position (reference panics) */
+int svo_octree_unsubdivide(svo_octree *o, size_t node);
+void svo_octree_find_voxel(const svo_octree *o, const float pos[3], int64_t max_depth, uint64_t *index,
+                           uint32_t *depth, float node_pos[3]);
+/* expanded(size): zero-padded copy; out holds size words; returns -1 if size < len */
+int svo_octree_expanded(const svo_octree *o, size_t size, uint32_t *out);
+void svo_octree_pos_offset(uint32_t child_index, uint32_t depth, float out[3]);
+size_t svo_octree_holes(const svo_octree *o);
+
+/* ---- camera ---- */
+void svo_camera_matrices(const float pos[3], const float look[3], float fov_deg, float width, float height,
+                         float camera[16], float camera_inverse[16]);
+
+/* ---- deterministic scene generators (benchmark inputs) ---- */
+typedef struct svo_terrain_params {
+    uint32_t seed;
+    uint32_t max_depth;      /* finest level (<= 20) */
+    float cam[3];            /* LOD centre, world coordinates */
+    float lod_c;             /* a mixed node at distance r is refined while 2^level < lod_c / r */
+    uint32_t min_depth;      /* always refine to at least this level */
+    uint64_t max_words;      /* hard cap on the node array (<= 2^27) */
+} svo_terrain_params;
+/* Returns the number of words written (BFS order, root group at 0); out holds cap words. */
+uint64_t svo_gen_terrain(const svo_terrain_params *p, uint32_t *out, uint64_t cap);
+/* terrain height (in finest-voxel units, 0..2^max_depth) of column (X, Z) at the finest level */
+int32_t svo_gen_terrain_height(uint32_t seed, uint32_t max_depth, uint32_t X, uint32_t Z);
+/* Sierpinski-tetrahedron octree (children of even coordinate parity survive), refined by the same
+ * distance rule, so a depth-20 tree stays under the 2^27-word layout cap.  Words returned. */
+uint64_t svo_gen_fractal(const svo_terrain_params *p, uint32_t *out, uint64_t cap);
+/* random sparse tree for tests: each child is interior with probability p_split (until max_depth),
+ * else solid with probability p_solid */
+uint64_t svo_gen_random(uint32_t seed, uint32_t max_depth, float p_split, float p_solid, uint64_t max_words,
+                        uint32_t *out, uint64_t cap);
+/* maximum leaf depth of a node array (BFS over the array; 0 for malformed) */
+uint32_t svo_nodes_max_depth(const uint32_t *words, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,449 @@
+// svo_abi.cpp -- the extern "C" boundary declared in include/svo_hip.h: device context, node
+// buffer, uniforms, trace / scan dispatch.  Replaces the wgpu plumbing of the reference's gpu.rs,
+// and the device halves of render.rs / compute.rs (citations in the header).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "svo_device.h"
+#include "svo_hip.h"
+
+struct svo_ctx {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // node buffer (render.rs:53-61)
+    uint32_t *nodes = nullptr;
+    size_t capacity = 0;
+    bool nodes_owned = false;
+    bool top_dirty = true;
+    uint32_t *top_table = nullptr;
+    uint32_t *status = nullptr;        // device error word
+    uint32_t *work_counter = nullptr;  // device strip counter
+    // scan lists (compute.rs:46-64): slot 0 = count
+    uint32_t *scan_sub = nullptr, *scan_unsub = nullptr;
+    size_t scan_capacity = 0;
+    // host staging for svo_render_host
+    void *stage = nullptr;
+    size_t stage_bytes = 0;
+    svo_uniforms uniforms{};
+    bool have_uniforms = false;
+    // options
+    int variant = SVO_VARIANT_STACK;
+    int grid_blocks = 0;
+    uint32_t refill_min = 16;
+    uint32_t strip_items = 64;
+    bool dynamic_strips = true;
+    bool timing = false;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool ev_valid = false;
+    std::string err;
+};
+
+namespace {
+
+constexpr size_t kScanCapacity = 1024000;  // adaptive.rs:3-4
+
+int fail(svo_ctx *ctx, int code, const char *what) {
+    if (ctx) ctx->err = what;
+    return code;
+}
+
+int fail_hip(svo_ctx *ctx, hipError_t e, const char *what) {
+    if (ctx) ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+    return SVO_ERR_HIP;
+}
+
+#define HIP_TRY(ctx, expr)                                   \
+    do {                                                     \
+        hipError_t e_ = (expr);                              \
+        if (e_ != hipSuccess) return fail_hip(ctx, e_, #expr); \
+    } while (0)
+
+int bind(svo_ctx *ctx) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return SVO_OK;
+}
+
+int ensure_top_table(svo_ctx *ctx) {
+    if (!ctx->top_dirty) return SVO_OK;
+    HIP_TRY(ctx, svo::launch_build_top_table(ctx->nodes, (uint32_t)ctx->capacity, ctx->top_table, ctx->stream));
+    ctx->top_dirty = false;
+    return SVO_OK;
+}
+
+int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo_hit *hits, uint32_t *rgba) {
+    if (!ctx->nodes) return fail(ctx, SVO_ERR_STATE, "svo_nodes_alloc / svo_nodes_bind_device not called");
+    if (work.mode != 2 && !ctx->have_uniforms) return fail(ctx, SVO_ERR_STATE, "svo_set_uniforms not called");
+    if (!hits) return fail(ctx, SVO_ERR_ARG, "hits_out is NULL");
+    if (rgba) return fail(ctx, SVO_ERR_ARG, "rgba_out: shading kernel not built yet");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (ctx->variant == SVO_VARIANT_STACK) {
+        rc = ensure_top_table(ctx);
+        if (rc) return rc;
+    }
+    svo::TraceArgs a{};
+    a.nodes = ctx->nodes;
+    a.n_words = (uint32_t)ctx->capacity;
+    a.top_table = ctx->top_table;
+    a.u = ctx->uniforms;
+    a.work = work;
+    a.rays = rays;
+    a.hits = hits;
+    a.rgba = rgba;
+    a.status = ctx->status;
+    a.refill_min = ctx->refill_min;
+    svo::LaunchInfo li{};
+    li.variant = ctx->variant;
+    li.grid_blocks = ctx->grid_blocks;
+    li.num_cus = ctx->num_cus;
+    li.strip_items = ctx->strip_items;
+    li.work_counter = ctx->dynamic_strips ? ctx->work_counter : nullptr;
+    if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    HIP_TRY(ctx, svo::launch_trace(a, li, ctx->stream));
+    if (ctx->timing) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+        ctx->ev_valid = true;
+    }
+    return SVO_OK;
+}
+
+int make_rect_work(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                   svo::WorkDesc &work) {
+    if (!ctx->have_uniforms) return fail(ctx, SVO_ERR_STATE, "svo_set_uniforms not called");
+    if ((float)width != ctx->uniforms.dimensions[0] || (float)height != ctx->uniforms.dimensions[1])
+        return fail(ctx, SVO_ERR_ARG, "width/height differ from uniforms.dimensions");
+    if (w == 0 || h == 0 || x0 + (uint64_t)w > width || y0 + (uint64_t)h > height)
+        return fail(ctx, SVO_ERR_ARG, "tile rectangle outside the frame");
+    if ((uint64_t)w * h > (1u << 26)) return fail(ctx, SVO_ERR_ARG, "tile too large");
+    work = svo::WorkDesc{};
+    work.mode = 0;
+    work.x0 = x0; work.y0 = y0; work.w = w; work.h = h;
+    work.bpr = (w + 7) / 8;
+    work.bprect = work.bpr * ((h + 7) / 8);
+    work.n_rects = 1;
+    work.tiles_x = 1;
+    work.n_items = work.bprect * 64u;
+    return SVO_OK;
+}
+
+int ensure_stage(svo_ctx *ctx, size_t bytes) {
+    if (ctx->stage_bytes >= bytes) return SVO_OK;
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    ctx->stage = nullptr;
+    ctx->stage_bytes = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->stage, bytes));
+    ctx->stage_bytes = bytes;
+    return SVO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int svo_ctx_create(int hip_device, svo_ctx **out) {
+    if (!out) return SVO_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SVO_ERR_NO_DEVICE;
+    if (hip_device < 0 || hip_device >= n) return SVO_ERR_ARG;
+    svo_ctx *ctx = new (std::nothrow) svo_ctx();
+    if (!ctx) return SVO_ERR_HIP;
+    ctx->device = hip_device;
+    hipError_t e = hipSetDevice(hip_device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, hip_device);
+    if (e == hipSuccess) {
+        ctx->num_cus = prop.multiProcessorCount;
+        e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->top_table, svo::kTopEntries * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->status, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(ctx->status, 0, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_start);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_stop);
+    if (e != hipSuccess) {
+        svo_ctx_destroy(ctx);
+        return SVO_ERR_HIP;
+    }
+    ctx->work_counter = ctx->status + 1;
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return SVO_OK;
+}
+
+int svo_ctx_destroy(svo_ctx *ctx) {
+    if (!ctx) return SVO_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->nodes && ctx->nodes_owned) (void)hipFree(ctx->nodes);
+    if (ctx->top_table) (void)hipFree(ctx->top_table);
+    if (ctx->status) (void)hipFree(ctx->status);
+    if (ctx->scan_sub) (void)hipFree(ctx->scan_sub);
+    if (ctx->scan_unsub) (void)hipFree(ctx->scan_unsub);
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return SVO_OK;
+}
+
+int svo_ctx_set_stream(svo_ctx *ctx, void *hip_stream) {
+    if (!ctx) return SVO_ERR_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SVO_OK;
+}
+
+int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
+    if (!ctx) return SVO_ERR_ARG;
+    switch (option) {
+        case SVO_OPT_VARIANT:
+            if (value != SVO_VARIANT_RESTART && value != SVO_VARIANT_STACK) return fail(ctx, SVO_ERR_ARG, "unknown variant");
+            ctx->variant = (int)value;
+            return SVO_OK;
+        case SVO_OPT_TIMING:
+            ctx->timing = value != 0;
+            ctx->ev_valid = false;
+            return SVO_OK;
+        case SVO_OPT_GRID_BLOCKS:
+            if (value < 0 || value > 65535) return fail(ctx, SVO_ERR_ARG, "grid_blocks out of range");
+            ctx->grid_blocks = (int)value;
+            return SVO_OK;
+        case SVO_OPT_REFILL_MIN:
+            if (value < 1 || value > 64) return fail(ctx, SVO_ERR_ARG, "refill_min must be 1..64");
+            ctx->refill_min = (uint32_t)value;
+            return SVO_OK;
+        case SVO_OPT_STRIP_ITEMS:
+            if (value < 64 || value > (1 << 20) || (value & 63)) return fail(ctx, SVO_ERR_ARG, "strip_items must be a multiple of 64");
+            ctx->strip_items = (uint32_t)value;
+            return SVO_OK;
+        case SVO_OPT_DYNAMIC_STRIPS:
+            ctx->dynamic_strips = value != 0;
+            return SVO_OK;
+        default:
+            return fail(ctx, SVO_ERR_ARG, "unknown option");
+    }
+}
+
+const char *svo_last_error(const svo_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int svo_sync(svo_ctx *ctx) {
+    if (!ctx) return SVO_ERR_ARG;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // surface device-side errors raised by trace kernels
+    uint32_t st = 0;
+    HIP_TRY(ctx, hipMemcpy(&st, ctx->status, sizeof(st), hipMemcpyDeviceToHost));
+    if (st & 1u) {
+        HIP_TRY(ctx, hipMemset(ctx->status, 0, sizeof(uint32_t)));
+        return fail(ctx, SVO_ERR_STATE,
+                    "octree deeper than 24 levels met by the STACK variant (rays report the step-limit "
+                    "sentinel); use SVO_VARIANT_RESTART for such trees");
+    }
+    return SVO_OK;
+}
+
+int svo_nodes_alloc(svo_ctx *ctx, size_t capacity_words) {
+    if (!ctx) return SVO_ERR_ARG;
+    if (capacity_words < 8 || capacity_words > (size_t)SVO_VOXEL_OFFSET)
+        return fail(ctx, SVO_ERR_ARG, "capacity_words must be in [8, 2^27]");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->nodes && ctx->nodes_owned) (void)hipFree(ctx->nodes);
+    ctx->nodes = nullptr;
+    ctx->capacity = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->nodes, capacity_words * sizeof(uint32_t)));
+    ctx->nodes_owned = true;
+    ctx->capacity = capacity_words;
+    // Octree::expanded zero-fills the tail (octree.rs:143-148)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->nodes, 0, capacity_words * sizeof(uint32_t), ctx->stream));
+    ctx->top_dirty = true;
+    return SVO_OK;
+}
+
+int svo_nodes_bind_device(svo_ctx *ctx, uint32_t *device_words, size_t capacity_words) {
+    if (!ctx || !device_words) return SVO_ERR_ARG;
+    if (capacity_words < 8 || capacity_words > (size_t)SVO_VOXEL_OFFSET)
+        return fail(ctx, SVO_ERR_ARG, "capacity_words must be in [8, 2^27]");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->nodes && ctx->nodes_owned) (void)hipFree(ctx->nodes);
+    ctx->nodes = device_words;
+    ctx->nodes_owned = false;
+    ctx->capacity = capacity_words;
+    ctx->top_dirty = true;
+    return SVO_OK;
+}
+
+int svo_nodes_write(svo_ctx *ctx, size_t word_offset, const uint32_t *host_words, size_t n) {
+    if (!ctx || (!host_words && n)) return SVO_ERR_ARG;
+    if (!ctx->nodes) return fail(ctx, SVO_ERR_STATE, "svo_nodes_alloc not called");
+    if (word_offset > ctx->capacity || n > ctx->capacity - word_offset)
+        return fail(ctx, SVO_ERR_ARG, "write past the node buffer capacity");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->nodes + word_offset, host_words, n * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                    ctx->stream));
+    ctx->top_dirty = true;
+    return SVO_OK;
+}
+
+int svo_nodes_read(svo_ctx *ctx, size_t word_offset, uint32_t *host_words, size_t n) {
+    if (!ctx || (!host_words && n)) return SVO_ERR_ARG;
+    if (!ctx->nodes) return fail(ctx, SVO_ERR_STATE, "svo_nodes_alloc not called");
+    if (word_offset > ctx->capacity || n > ctx->capacity - word_offset)
+        return fail(ctx, SVO_ERR_ARG, "read past the node buffer capacity");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n) {
+        HIP_TRY(ctx, hipMemcpyAsync(host_words, ctx->nodes + word_offset, n * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SVO_OK;
+}
+
+int svo_nodes_device_ptr(svo_ctx *ctx, uint32_t **out, size_t *capacity_words) {
+    if (!ctx || !out) return SVO_ERR_ARG;
+    *out = ctx->nodes;
+    if (capacity_words) *capacity_words = ctx->capacity;
+    ctx->top_dirty = true;  // the caller may write through the pointer
+    return SVO_OK;
+}
+
+int svo_set_uniforms(svo_ctx *ctx, const svo_uniforms *u) {
+    if (!ctx || !u) return SVO_ERR_ARG;
+    ctx->uniforms = *u;
+    ctx->have_uniforms = true;
+    return SVO_OK;
+}
+
+int svo_render(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t tile_w,
+               uint32_t tile_h, svo_hit *hits_out, uint32_t *rgba_out) {
+    if (!ctx) return SVO_ERR_ARG;
+    svo::WorkDesc work;
+    int rc = make_rect_work(ctx, width, height, x0, y0, tile_w, tile_h, work);
+    if (rc) return rc;
+    return trace_common(ctx, work, nullptr, hits_out, rgba_out);
+}
+
+int svo_render_host(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t tile_w,
+                    uint32_t tile_h, svo_hit *hits_out, uint32_t *rgba_out) {
+    if (!ctx) return SVO_ERR_ARG;
+    if (!hits_out) return fail(ctx, SVO_ERR_ARG, "hits_out is NULL");
+    svo::WorkDesc work;
+    int rc = make_rect_work(ctx, width, height, x0, y0, tile_w, tile_h, work);
+    if (rc) return rc;
+    size_t n = (size_t)tile_w * tile_h;
+    rc = bind(ctx);
+    if (rc) return rc;
+    rc = ensure_stage(ctx, n * sizeof(svo_hit));
+    if (rc) return rc;
+    rc = trace_common(ctx, work, nullptr, (svo_hit *)ctx->stage, rgba_out ? nullptr : nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(hits_out, ctx->stage, n * sizeof(svo_hit), hipMemcpyDeviceToHost, ctx->stream));
+    return svo_sync(ctx);
+}
+
+int svo_render_tiles(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
+                     uint32_t first_tile, uint32_t tile_stride, svo_hit *hits_out, uint32_t *rgba_out) {
+    if (!ctx) return SVO_ERR_ARG;
+    if (!ctx->have_uniforms) return fail(ctx, SVO_ERR_STATE, "svo_set_uniforms not called");
+    if ((float)width != ctx->uniforms.dimensions[0] || (float)height != ctx->uniforms.dimensions[1])
+        return fail(ctx, SVO_ERR_ARG, "width/height differ from uniforms.dimensions");
+    if (tile_w == 0 || tile_h == 0 || width % tile_w || height % tile_h)
+        return fail(ctx, SVO_ERR_ARG, "frame must be a whole number of tiles");
+    if (tile_stride == 0) return fail(ctx, SVO_ERR_ARG, "tile_stride must be >= 1");
+    uint32_t tiles_x = width / tile_w, tiles = tiles_x * (height / tile_h);
+    svo::WorkDesc work{};
+    work.mode = 1;
+    work.w = tile_w; work.h = tile_h;
+    work.bpr = (tile_w + 7) / 8;
+    work.bprect = work.bpr * ((tile_h + 7) / 8);
+    work.n_rects = first_tile < tiles ? (tiles - first_tile + tile_stride - 1) / tile_stride : 0;
+    work.tiles_x = tiles_x;
+    work.first_tile = first_tile;
+    work.tile_stride = tile_stride;
+    uint64_t items = (uint64_t)work.n_rects * work.bprect * 64u;
+    if (items > (1u << 26)) return fail(ctx, SVO_ERR_ARG, "too many pixels for one call");
+    work.n_items = (uint32_t)items;
+    return trace_common(ctx, work, nullptr, hits_out, rgba_out);
+}
+
+int svo_trace_rays(svo_ctx *ctx, const float *rays, size_t n_rays, svo_hit *hits_out) {
+    if (!ctx || (!rays && n_rays)) return SVO_ERR_ARG;
+    if (n_rays > (1u << 26)) return fail(ctx, SVO_ERR_ARG, "too many rays for one call");
+    svo::WorkDesc work{};
+    work.mode = 2;
+    work.n_items = (uint32_t)n_rays;
+    work.bpr = work.bprect = work.tiles_x = 1;
+    return trace_common(ctx, work, rays, hits_out, nullptr);
+}
+
+int svo_last_render_ms(svo_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return SVO_ERR_ARG;
+    if (!ctx->timing || !ctx->ev_valid) return fail(ctx, SVO_ERR_STATE, "no timed launch (set SVO_OPT_TIMING=1 first)");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    return SVO_OK;
+}
+
+int svo_scan_dispatch(svo_ctx *ctx, uint32_t node_length) {
+    if (!ctx) return SVO_ERR_ARG;
+    if (!ctx->nodes) return fail(ctx, SVO_ERR_STATE, "svo_nodes_alloc not called");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!ctx->scan_sub) {
+        // Compute::new: two lists of 1 024 000 words, zero-initialised (compute.rs:46-64)
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->scan_sub, kScanCapacity * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->scan_unsub, kScanCapacity * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->scan_sub, 0, sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->scan_unsub, 0, sizeof(uint32_t), ctx->stream));
+        ctx->scan_capacity = kScanCapacity;
+    }
+    uint32_t n = node_length < ctx->capacity ? node_length : (uint32_t)ctx->capacity;
+    HIP_TRY(ctx, svo::launch_scan(ctx->nodes, n, node_length, ctx->scan_sub, ctx->scan_unsub,
+                                  (uint32_t)ctx->scan_capacity, ctx->stream));
+    return SVO_OK;
+}
+
+int svo_scan_read(svo_ctx *ctx, uint32_t *sub, uint32_t *n_sub, uint32_t *unsub, uint32_t *n_unsub, size_t capacity) {
+    if (!ctx || !sub || !unsub || !n_sub || !n_unsub || capacity < 1) return SVO_ERR_ARG;
+    if (!ctx->scan_sub) return fail(ctx, SVO_ERR_STATE, "svo_scan_dispatch not called");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    uint32_t counts[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(&counts[0], ctx->scan_sub, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&counts[1], ctx->scan_unsub, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // adaptive.rs:22,86: len = min(count, MAX - 1)
+    uint32_t ls = counts[0] < ctx->scan_capacity - 1 ? counts[0] : (uint32_t)ctx->scan_capacity - 1;
+    uint32_t lu = counts[1] < ctx->scan_capacity - 1 ? counts[1] : (uint32_t)ctx->scan_capacity - 1;
+    if (ls + 1 > capacity) ls = (uint32_t)capacity - 1;
+    if (lu + 1 > capacity) lu = (uint32_t)capacity - 1;
+    sub[0] = ls;
+    unsub[0] = lu;
+    if (ls) HIP_TRY(ctx, hipMemcpyAsync(sub + 1, ctx->scan_sub + 1, ls * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (lu) HIP_TRY(ctx, hipMemcpyAsync(unsub + 1, ctx->scan_unsub + 1, lu * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    // adaptive.rs:23,87: reset the atomic counter
+    HIP_TRY(ctx, hipMemsetAsync(ctx->scan_sub, 0, sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->scan_unsub, 0, sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *n_sub = ls;
+    *n_unsub = lu;
+    return SVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// svo_device.h -- internal launch interface between the C ABI (svo_abi.cpp) and the gfx950
+// kernels (svo_kernels.hip).  Not part of the public boundary (include/svo_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "svo_hip.h"
+
+namespace svo {
+
+constexpr uint32_t kVoxelOffset = 134217728u;  // octree.rs:5
+constexpr uint32_t kMaxDescent = 31;           // descent guard (see oracle/svo_oracle.c)
+constexpr int kTopLevels = 4;                  // K: octree levels folded into the LDS top table
+constexpr int kTopEntries = 1 << (3 * kTopLevels);
+constexpr int kPathBits = 24;                  // D: integer path-code bits per axis
+
+// Top-table entry (one per level-K cell, index = cx << 2K | cy << K | cz):
+//   bit 31 = 0: bits 0..26 = index of the child group at level K+1 (descent continues there)
+//   bit 31 = 1: a leaf above level K+1: bits 0..26 leaf word index, bits 27..29 depth (1..K),
+//               bit 30 = leaf is solid (pointer - VOXEL_OFFSET > 0)
+constexpr uint32_t kTopLeaf = 0x80000000u;
+constexpr uint32_t kTopSolid = 0x40000000u;
+
+// Work decomposition: a list of equally sized pixel rectangles, each cut into 8x8 pixel blocks.
+// Item q (one pixel slot): rect = q / (64 * blocks_per_rect); block and lane follow.
+struct WorkDesc {
+    uint32_t mode;        // 0: one rectangle at (x0, y0); 1: tiles first_tile + k * tile_stride; 2: explicit rays
+    uint32_t x0, y0;      // mode 0 origin
+    uint32_t w, h;        // rectangle size in pixels
+    uint32_t bpr;         // 8x8 blocks per rectangle row
+    uint32_t bprect;      // blocks per rectangle
+    uint32_t n_rects;
+    uint32_t tiles_x;     // mode 1: tiles per frame row
+    uint32_t first_tile, tile_stride;
+    uint32_t n_items;     // mode 0/1: n_rects * bprect * 64; mode 2: n_rays
+};
+
+struct TraceArgs {
+    const uint32_t *nodes;
+    uint32_t n_words;
+    const uint32_t *top_table;  // kTopEntries words (device) or nullptr
+    svo_uniforms u;
+    WorkDesc work;
+    const float *rays;          // mode 2
+    svo_hit *hits;              // may be nullptr
+    uint32_t *rgba;             // may be nullptr
+    uint32_t *status;           // device word: bit 0 set when a STACK-variant descent exceeded kPathBits
+    uint32_t refill_min;
+};
+
+struct LaunchInfo {
+    int variant;
+    int grid_blocks;         // 0 = auto
+    int num_cus;
+    uint32_t strip_items;    // STACK: pixel slots a wave claims at a time (multiple of 64)
+    uint32_t *work_counter;  // STACK: device word for dynamic strip claiming, or nullptr (static round-robin)
+};
+
+hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint32_t *top_table,
+                                  hipStream_t stream);
+hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream);
+hipError_t launch_scan(const uint32_t *nodes, uint32_t n_words, uint32_t node_length, uint32_t *sub,
+                       uint32_t *unsub, uint32_t capacity, hipStream_t stream);
+
+}  // namespace svo

@@ -1,0 +1,52 @@
+"""Device context: replaces reference src/gpu.rs (wgpu instance/adapter/device/queue) with a
+HIP context handle from the C ABI."""
+import ctypes as C
+
+from ._lib import SvoError, lib
+
+OPT_VARIANT, OPT_TIMING, OPT_GRID_BLOCKS, OPT_REFILL_MIN, OPT_STRIP_ITEMS, OPT_DYNAMIC_STRIPS = range(6)
+VARIANT_RESTART, VARIANT_STACK = 0, 1
+
+
+class Gpu:
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        rc = lib().svo_ctx_create(device, C.byref(h))
+        if rc != 0:
+            # the reference unwraps (gpu.rs:24,39): fail loudly, there is no fallback device
+            raise SvoError(f"svo_ctx_create(device={device}) failed with status {rc} (no usable HIP device?)")
+        self._h = h
+        self.device = device
+        if stream is not None:
+            self.set_stream(stream)
+
+    @classmethod
+    def new(cls, device=0):
+        return cls(device)
+
+    def check(self, rc):
+        if rc != 0:
+            raise SvoError(f"status {rc}: {lib().svo_last_error(self._h).decode()}")
+
+    def set_stream(self, hip_stream):
+        self.check(lib().svo_ctx_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_option(self, option, value):
+        self.check(lib().svo_set_option(self._h, option, int(value)))
+
+    def sync(self):
+        """device.poll(Maintain::Wait)"""
+        self.check(lib().svo_sync(self._h))
+
+    def last_render_ms(self):
+        ms = C.c_float()
+        self.check(lib().svo_last_render_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().svo_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

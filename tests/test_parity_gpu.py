@@ -1,0 +1,220 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_hits_equal, set_uniforms_from_oracle
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [0, 1]  # RESTART, STACK
+
+
+def _render(pkg, gpu, words, u, variant, capacity=None, tile=None):
+    render = pkg.Render(gpu, (int(u.dimensions[0]), int(u.dimensions[1])), words,
+                        capacity=capacity or max(words.size, 64))
+    set_uniforms_from_oracle(render, u)
+    gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+    hits = render.render(tile=tile)
+    gpu.sync()
+    return pkg.render.hits_to_numpy(hits)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_config1_small_vox_golden(pkg, gpu, O, small_words, variant):
+    """Config 1 (small.vox, 256x256, default camera) against the committed golden records."""
+    z = np.load(f"{GOLDEN}/config1_small_256.npz")
+    u = O.make_uniforms(width=256, height=256, flags=O.F_PAUSE_ADAPTIVE)
+    u.camera[:] = z["camera"].tolist()
+    u.camera_inverse[:] = z["camera_inverse"].tolist()
+    got = _render(pkg, gpu, small_words, u, variant)
+    want = z["hits"].view(pkg.HIT_DTYPE).reshape(-1)
+    assert_hits_equal(got, want, "config1 golden")
+    assert_hits_equal(got, O.trace_frame(small_words, u, threads=4), "config1 oracle")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("pose", [((0.1, 0.2, -1.5), (0.0, 0.0, 1.5)), ((1.3, 0.9, 1.2), (-1.0, -0.6, -1.0)),
+                                  ((0.02, 0.31, 0.05), (0.3, -0.2, 1.0)), ((-1.6, 0.1, 0.2), (1.0, 0.0, 0.0))])
+def test_monu9_frame(pkg, gpu, O, monu9_words, variant, pose):
+    """Config 2 geometry at 480x270 (the oracle finishes in seconds); poses outside, inside, axis-aligned."""
+    u = O.make_uniforms(pos=pose[0], look=pose[1], width=480, height=270, flags=O.F_PAUSE_ADAPTIVE)
+    got = _render(pkg, gpu, monu9_words, u, variant)
+    assert_hits_equal(got, O.trace_frame(monu9_words, u, threads=8), f"monu9 pose {pose}")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_monu9_golden_samples_1080p(pkg, gpu, O, monu9_words, variant):
+    """Config 2 at its full 1920x1080 size: 4096 committed oracle samples."""
+    z = np.load(f"{GOLDEN}/config2_monu9_samples.npz")
+    u = O.make_uniforms(width=1920, height=1080, flags=O.F_PAUSE_ADAPTIVE)
+    u.camera[:] = z["camera"].tolist()
+    u.camera_inverse[:] = z["camera_inverse"].tolist()
+    got = _render(pkg, gpu, monu9_words, u, variant).reshape(1080, 1920)
+    sel = got[z["py"], z["px"]]
+    assert_hits_equal(sel, z["hits"].view(pkg.HIT_DTYPE).reshape(-1), "monu9 1080p samples")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("misc_bool", [False, True])
+def test_random_trees(pkg, gpu, O, variant, misc_bool):
+    """Seeded random sparse trees (depth 9), both tie-break modes (shader.wgsl:138-150)."""
+    flags = O.F_PAUSE_ADAPTIVE | (O.F_MISC_BOOL if misc_bool else 0)
+    for seed in (1, 2):
+        words = pkg.scenes.random_tree(seed=seed, max_depth=9, p_split=0.45, p_solid=0.25, max_words=1 << 20)
+        u = O.make_uniforms(pos=(0.3, 0.4, -1.7), look=(-0.1, -0.2, 1.0), width=320, height=200, flags=flags)
+        got = _render(pkg, gpu, words, u, variant)
+        assert_hits_equal(got, O.trace_frame(words, u, threads=8), f"random tree seed {seed}")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_deep_terrain_depth16(pkg, gpu, O, variant):
+    """Depth-16 LOD terrain (the benchmark scene family at reduced size), camera inside the cube."""
+    cam, look = pkg.scenes.terrain_camera(0, 16)
+    words = pkg.scenes.terrain(seed=0, max_depth=16, cam=cam, lod_c=150.0, max_words=4_000_000)
+    assert pkg.scenes.max_depth(words) == 16
+    u = O.make_uniforms(pos=cam, look=look, width=384, height=216, flags=O.F_PAUSE_ADAPTIVE)
+    got = _render(pkg, gpu, words, u, variant)
+    assert_hits_equal(got, O.trace_frame(words, u, threads=8), "terrain depth 16")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_explicit_rays_edge_cases(pkg, gpu, O, monu9_words, variant):
+    """Axis-aligned rays (zero direction components, shader.wgsl:193-194 vs :67-72), rays that miss,
+    rays starting inside, on faces, with NaN/inf components, plus random rays."""
+    import torch
+    rng = np.random.default_rng(5)
+    rays = [
+        [0.5, 0.5, -3, 0, 0, 1], [0.5, 0.5, -3, 0, 0, -1], [-0.5, -0.5, -3, 0, 0, 1], [0.1, 0.2, 0.3, 1, 0, 0],
+        [0.1, 0.2, 0.3, 0, -1, 0], [-1.0, 0.0, 0.0, 1, 0, 0], [1.0, 0.0, 0.0, -1, 0, 0], [0.0, 0.0, 0.0, 0, 0, 0],
+        [0, 5, 0, 0, -1, 0], [0, 5, 0, 0, 1, 0], [3, 3, 3, -1, -1, -1], [-1, -1, -1, 1, 1, 1],
+        [np.nan, 0, 0, 1, 0, 0], [0, 0, -2, np.nan, 0, 1], [0, 0, -2, 0, 0, np.inf], [np.inf, 0, 0, -1, 0, 0],
+        [0.25, 0.25, -1.0000001, 0, 0, 1], [0.999999, 0.999999, 0.999999, 1, 1, 1],
+    ]
+    rnd = np.concatenate([rng.uniform(-2, 2, (4000, 3)), rng.normal(size=(4000, 3))], axis=1)
+    rnd[:, 3:] /= np.linalg.norm(rnd[:, 3:], axis=1, keepdims=True)
+    inside = np.concatenate([rng.uniform(-1, 1, (4000, 3)), rng.normal(size=(4000, 3))], axis=1)
+    axis = inside.copy()
+    axis[:, 3:] = np.eye(3)[rng.integers(0, 3, 4000)] * rng.choice([-1.0, 1.0], (4000, 1))
+    rays = np.concatenate([np.array(rays, dtype=np.float32), rnd.astype(np.float32), inside.astype(np.float32),
+                           axis.astype(np.float32)])
+    render = pkg.Render(gpu, (8, 8), monu9_words, capacity=monu9_words.size)
+    gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+    for flags in (O.F_PAUSE_ADAPTIVE, O.F_PAUSE_ADAPTIVE | O.F_MISC_BOOL):
+        render.uniforms.flags = flags
+        render.upload_uniforms()
+        got = pkg.render.hits_to_numpy(render.trace_rays(torch.from_numpy(rays).cuda()))
+        gpu.sync()
+        assert_hits_equal(got, O.trace_rays(monu9_words, rays, flags=flags, threads=8), f"explicit rays flags={flags}")
+
+
+def test_known_answers_single_level(pkg, gpu, O):
+    """SURVEY 8c KATs 4-7 on the device: one-level tree with only child 7 solid."""
+    import torch
+    words = np.array([0x80000000] * 7 + [0x8FF00000], dtype=np.uint32)
+    rays = np.array([[0.5, 0.5, -3, 0, 0, 1], [0.5, 0.5, -3, 0, 0, -1], [-0.5, -0.5, -3, 0, 0, 1]], dtype=np.float32)
+    render = pkg.Render(gpu, (8, 8), words, capacity=64)
+    render.uniforms.flags = O.F_PAUSE_ADAPTIVE
+    render.upload_uniforms()
+    for variant in VARIANTS:
+        gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+        h = pkg.render.hits_to_numpy(render.trace_rays(torch.from_numpy(rays).cuda()))
+        gpu.sync()
+        assert h["value"].tolist() == [7, 0, 0x20202000]
+        assert h["t"].tolist() == [3.0, 0.0, 4.0]
+        assert (h["info"] & 0xFF).tolist() == [1, 0, 1]          # steps
+        assert ((h["info"] >> 8) & 0xFF).tolist() == [1, 0, 1]   # depth
+        assert ((h["info"] >> 16) & 1).tolist() == [1, 0, 0]     # hit
+        assert h["normal_bits"].tolist() == [2 << 4, 0, 0]       # (0, 0, -1)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_step_limit_and_malformed(pkg, gpu, O, variant):
+    """>100 steps sentinel (shader.wgsl:242-244) and a malformed array (zero words = a pointer cycle):
+    the kernel must terminate and report the sentinel like the oracle."""
+    z = np.load(f"{GOLDEN}/config1_small_256.npz")
+    want = z["hits"].view(pkg.HIT_DTYPE).reshape(-1)
+    assert (want["value"] == 0xFF000000).any(), "fixture should contain step-limit rays"
+    words = np.zeros(64, dtype=np.uint32)  # every word is 'interior -> group 0'
+    u = O.make_uniforms(width=64, height=64, flags=O.F_PAUSE_ADAPTIVE)
+    if variant == 1:
+        # STACK resolves 24 levels; deeper trees are refused loudly (the oracle's guard is at depth 31)
+        render = pkg.Render(gpu, (64, 64), words, capacity=64)
+        set_uniforms_from_oracle(render, u)
+        gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+        hits = render.render()
+        with pytest.raises(pkg.SvoError):
+            gpu.sync()
+        h = pkg.render.hits_to_numpy(hits)
+        inside = h["value"] != 0
+        assert (h["value"][inside] == 0xFF000000).all()
+    else:
+        got = _render(pkg, gpu, words, u, 0)
+        assert_hits_equal(got, O.trace_frame(words, u, threads=2), "malformed array")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_tiles_and_rectangles(pkg, gpu, O, monu9_words, variant):
+    """svo_render on sub-rectangles (ragged sizes) and svo_render_tiles sharding reassemble the frame."""
+    W, H = 256, 144
+    u = O.make_uniforms(width=W, height=H, flags=O.F_PAUSE_ADAPTIVE)
+    full = O.trace_frame(monu9_words, u, threads=8)
+    render = pkg.Render(gpu, (W, H), monu9_words, capacity=monu9_words.size)
+    set_uniforms_from_oracle(render, u)
+    gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+    for tile in [(0, 0, W, H), (3, 5, 61, 37), (200, 100, 56, 44), (255, 143, 1, 1), (0, 7, 256, 1)]:
+        got = pkg.render.hits_to_numpy(render.render(tile=tile))
+        gpu.sync()
+        x0, y0, w, h = tile
+        assert_hits_equal(got, full[y0:y0 + h, x0:x0 + w], f"rect {tile}")
+    tw, th, ranks = 64, 8, 3
+    tiles_x = W // tw
+    frame = np.zeros((H, W), dtype=pkg.HIT_DTYPE)
+    for r in range(ranks):
+        got = pkg.render.hits_to_numpy(render.render_tiles(tw, th, r, ranks)).reshape(-1, th, tw)
+        gpu.sync()
+        for k in range(got.shape[0]):
+            t = r + k * ranks
+            ty, tx = divmod(t, tiles_x)
+            frame[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = got[k]
+    assert_hits_equal(frame, full, "tile-sharded frame")
+    host = render.render_host(tile=(3, 5, 61, 37))
+    assert_hits_equal(host, full[5:42, 3:64], "render_host")
+
+
+def test_scan_kernel(pkg, gpu, O):
+    """Counter scan (compute.wgsl:26-47) against the oracle, as sets (the append order is unordered)."""
+    rng = np.random.default_rng(11)
+    n = 300_000
+    ptr = np.where(rng.random(n) < 0.4, rng.integers(0, 1 << 20, n), pkg.VOXEL_OFFSET + rng.integers(0, 1 << 24, n))
+    ptr[rng.random(n) < 0.05] = pkg.VOXEL_OFFSET  # empty leaves
+    words = ((ptr.astype(np.uint64) << 4) | rng.integers(0, 16, n).astype(np.uint64)).astype(np.uint32)
+    words[rng.random(n) < 0.02] = 0
+    render = pkg.Render(gpu, (8, 8), words, capacity=n + 1000)
+    compute = pkg.Compute(gpu, render)
+    for node_length in (n, n // 3, 0):
+        compute.update(node_length)
+        sub, unsub = compute.read_lists()
+        osub, ounsub = O.scan(words, node_length=node_length)
+        assert sorted(sub.tolist()) == osub[1:1 + osub[0]].tolist()
+        assert sorted(unsub.tolist()) == ounsub[1:1 + ounsub[0]].tolist()
+    compute.update(n)  # counters were reset by the read (adaptive.rs:23,87)
+    sub2, _ = compute.read_lists()
+    assert sub2.size == O.scan(words)[0][0]
+
+
+def test_error_paths(pkg, gpu):
+    """Call-order and argument errors come back as statuses, not aborts."""
+    g = pkg.Gpu(0)
+    with pytest.raises(pkg.SvoError):
+        g.check(pkg._lib.lib().svo_scan_dispatch(g._h, 8))  # no node buffer yet
+    render = pkg.Render(g, (16, 16), np.array([0x80000000] * 8, dtype=np.uint32), capacity=64)
+    with pytest.raises(pkg.SvoError):
+        render.render()  # uniforms not set
+    render.update(pkg.Settings(), pkg.Character())
+    with pytest.raises(pkg.SvoError):
+        render.render(tile=(8, 8, 16, 16))  # outside the frame
+    with pytest.raises(pkg.SvoError):
+        render.write_nodes(np.zeros(100, dtype=np.uint32))  # past capacity
+    with pytest.raises(pkg.SvoError):
+        g.set_option(pkg.gpu.OPT_VARIANT, 7)
+    g.close()
