@@ -82,7 +82,7 @@ typedef struct svo_ctx svo_ctx;
 
 typedef enum svo_option {
     SVO_OPT_VARIANT = 0,
-    SVO_OPT_TIMING = 1,      /* 1: bracket every trace launch with HIP events on the ctx stream */
+    SVO_OPT_TIMING = 1,      /* n > 0: bracket trace launches with HIP events on the launch stream (ring of n) */
     SVO_OPT_GRID_BLOCKS = 2, /* persistent grid size override (0 = auto) */
     SVO_OPT_REFILL_MIN = 3,  /* idle lanes needed before a wave refills */
     SVO_OPT_STRIP_ITEMS = 4, /* pixel slots a wave claims at a time (multiple of 64) */
@@ -91,8 +91,9 @@ typedef enum svo_option {
 
 int svo_ctx_create(int hip_device, svo_ctx **out);
 int svo_ctx_destroy(svo_ctx *ctx);
-/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the ctx's own. */
-int svo_ctx_set_stream(svo_ctx *ctx, void *hip_stream);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream; NULL is HIP's default
+ * stream), or, with use_own != 0, on the private non-blocking stream the ctx was created with. */
+int svo_ctx_set_stream(svo_ctx *ctx, void *hip_stream, int use_own);
 int svo_set_option(svo_ctx *ctx, int option, int64_t value);
 const char *svo_last_error(const svo_ctx *ctx);
 int svo_sync(svo_ctx *ctx);
@@ -126,8 +127,11 @@ int svo_render_tiles(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t til
 /* octree_ray over n explicit rays (6 floats each: pos.xyz, dir.xyz; device pointers). */
 int svo_trace_rays(svo_ctx *ctx, const float *rays, size_t n_rays, svo_hit *hits_out);
 
-/* Duration of the most recent trace launch in ms (needs SVO_OPT_TIMING=1); blocks on it. */
+/* Duration of the most recent trace launch in ms (needs SVO_OPT_TIMING > 0); blocks on it. */
 int svo_last_render_ms(svo_ctx *ctx, float *ms);
+/* Durations (ms, oldest first) of the trace launches recorded since the last collect, at most the
+ * ring size; blocks until they have finished and resets the record. */
+int svo_timing_collect(svo_ctx *ctx, float *ms_out, size_t cap, size_t *n_out);
 
 /* Counter scan (compute.wgsl).  Lists hold `capacity` words: slot 0 = count, slots 1.. = indices. */
 int svo_scan_dispatch(svo_ctx *ctx, uint32_t node_length);

@@ -21,6 +21,7 @@ from .gpu import Gpu
 from .render import Render, HIT_DTYPE, F_PAUSE_ADAPTIVE, F_SHOW_STEPS, F_SHOW_HITS, F_SHADOWS, F_MISC_BOOL
 from .compute import Compute
 from . import scenes
+from . import sharding
 
 __all__ = ["Gpu", "Render", "Compute", "Octree", "CpuOctree", "Voxel", "Uniforms", "Character", "Settings",
-           "SvoError", "VOXEL_OFFSET", "CHUNK_OFFSET", "HIT_DTYPE", "create_node", "camera_matrices", "scenes"]
+           "SvoError", "VOXEL_OFFSET", "CHUNK_OFFSET", "HIT_DTYPE", "create_node", "camera_matrices", "scenes", "sharding"]

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "svo_device.h"
 #include "svo_hip.h"
@@ -38,9 +39,9 @@ struct svo_ctx {
     uint32_t refill_min = 16;
     uint32_t strip_items = 64;
     bool dynamic_strips = true;
-    bool timing = false;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool ev_valid = false;
+    // launch timing: a ring of (start, stop) event pairs recorded around trace launches
+    std::vector<hipEvent_t> ev;  // 2 per slot
+    size_t ev_slots = 0, ev_count = 0;
     std::string err;
 };
 
@@ -104,11 +105,12 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     li.num_cus = ctx->num_cus;
     li.strip_items = ctx->strip_items;
     li.work_counter = ctx->dynamic_strips ? ctx->work_counter : nullptr;
-    if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    const size_t slot = ctx->ev_slots ? (ctx->ev_count % ctx->ev_slots) : 0;
+    if (ctx->ev_slots) HIP_TRY(ctx, hipEventRecord(ctx->ev[2 * slot], ctx->stream));
     HIP_TRY(ctx, svo::launch_trace(a, li, ctx->stream));
-    if (ctx->timing) {
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
-        ctx->ev_valid = true;
+    if (ctx->ev_slots) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[2 * slot + 1], ctx->stream));
+        ctx->ev_count++;
     }
     return SVO_OK;
 }
@@ -165,8 +167,6 @@ int svo_ctx_create(int hip_device, svo_ctx **out) {
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->top_table, svo::kTopEntries * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->status, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(ctx->status, 0, 2 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_start);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_stop);
     if (e != hipSuccess) {
         svo_ctx_destroy(ctx);
         return SVO_ERR_HIP;
@@ -187,16 +187,18 @@ int svo_ctx_destroy(svo_ctx *ctx) {
     if (ctx->scan_sub) (void)hipFree(ctx->scan_sub);
     if (ctx->scan_unsub) (void)hipFree(ctx->scan_unsub);
     if (ctx->stage) (void)hipFree(ctx->stage);
-    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
-    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SVO_OK;
 }
 
-int svo_ctx_set_stream(svo_ctx *ctx, void *hip_stream) {
+int svo_ctx_set_stream(svo_ctx *ctx, void *hip_stream, int use_own) {
     if (!ctx) return SVO_ERR_ARG;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // work queued on the old stream finishes first
+    ctx->stream = use_own ? ctx->own_stream : (hipStream_t)hip_stream;
     return SVO_OK;
 }
 
@@ -207,10 +209,20 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
             if (value != SVO_VARIANT_RESTART && value != SVO_VARIANT_STACK) return fail(ctx, SVO_ERR_ARG, "unknown variant");
             ctx->variant = (int)value;
             return SVO_OK;
-        case SVO_OPT_TIMING:
-            ctx->timing = value != 0;
-            ctx->ev_valid = false;
+        case SVO_OPT_TIMING: {
+            if (value < 0 || value > 65536) return fail(ctx, SVO_ERR_ARG, "timing ring size out of range");
+            int rc = bind(ctx);
+            if (rc) return rc;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            while (ctx->ev.size() < 2 * (size_t)value) {
+                hipEvent_t e;
+                HIP_TRY(ctx, hipEventCreate(&e));
+                ctx->ev.push_back(e);
+            }
+            ctx->ev_slots = (size_t)value;
+            ctx->ev_count = 0;
             return SVO_OK;
+        }
         case SVO_OPT_GRID_BLOCKS:
             if (value < 0 || value > 65535) return fail(ctx, SVO_ERR_ARG, "grid_blocks out of range");
             ctx->grid_blocks = (int)value;
@@ -392,11 +404,31 @@ int svo_trace_rays(svo_ctx *ctx, const float *rays, size_t n_rays, svo_hit *hits
 
 int svo_last_render_ms(svo_ctx *ctx, float *ms) {
     if (!ctx || !ms) return SVO_ERR_ARG;
-    if (!ctx->timing || !ctx->ev_valid) return fail(ctx, SVO_ERR_STATE, "no timed launch (set SVO_OPT_TIMING=1 first)");
+    if (!ctx->ev_slots || !ctx->ev_count) return fail(ctx, SVO_ERR_STATE, "no timed launch (set SVO_OPT_TIMING first)");
     int rc = bind(ctx);
     if (rc) return rc;
-    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
-    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    const size_t slot = (ctx->ev_count - 1) % ctx->ev_slots;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2 * slot + 1]));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev[2 * slot], ctx->ev[2 * slot + 1]));
+    return SVO_OK;
+}
+
+int svo_timing_collect(svo_ctx *ctx, float *ms_out, size_t cap, size_t *n_out) {
+    if (!ctx || !n_out || (!ms_out && cap)) return SVO_ERR_ARG;
+    *n_out = 0;
+    if (!ctx->ev_slots) return fail(ctx, SVO_ERR_STATE, "timing is off (set SVO_OPT_TIMING first)");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    size_t n = ctx->ev_count < ctx->ev_slots ? ctx->ev_count : ctx->ev_slots;
+    if (n > cap) n = cap;
+    const size_t first = ctx->ev_count - n;
+    for (size_t i = 0; i < n; i++) {
+        const size_t slot = (first + i) % ctx->ev_slots;
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2 * slot + 1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms_out[i], ctx->ev[2 * slot], ctx->ev[2 * slot + 1]));
+    }
+    *n_out = n;
+    ctx->ev_count = 0;
     return SVO_OK;
 }
 

@@ -17,8 +17,10 @@ class Gpu:
             raise SvoError(f"svo_ctx_create(device={device}) failed with status {rc} (no usable HIP device?)")
         self._h = h
         self.device = device
-        if stream is not None:
-            self.set_stream(stream)
+        # torch allocates and copies on its current stream: launch there so tensors handed to the
+        # C ABI are ordered with the kernels that read or write them
+        import torch
+        self.set_stream(stream if stream is not None else torch.cuda.current_stream(device).cuda_stream)
 
     @classmethod
     def new(cls, device=0):
@@ -29,7 +31,11 @@ class Gpu:
             raise SvoError(f"status {rc}: {lib().svo_last_error(self._h).decode()}")
 
     def set_stream(self, hip_stream):
-        self.check(lib().svo_ctx_set_stream(self._h, C.c_void_p(hip_stream)))
+        """hip_stream: a hipStream_t handle as int (0 = HIP's default stream)"""
+        self.check(lib().svo_ctx_set_stream(self._h, C.c_void_p(hip_stream), 0))
+
+    def use_own_stream(self):
+        self.check(lib().svo_ctx_set_stream(self._h, None, 1))
 
     def set_option(self, option, value):
         self.check(lib().svo_set_option(self._h, option, int(value)))
@@ -42,6 +48,14 @@ class Gpu:
         ms = C.c_float()
         self.check(lib().svo_last_render_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def timing_collect(self, cap=65536):
+        """durations (ms) of the trace launches recorded since the last collect"""
+        import numpy as np
+        buf = np.empty(cap, dtype=np.float32)
+        n = C.c_size_t()
+        self.check(lib().svo_timing_collect(self._h, buf.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n)))
+        return buf[:n.value].copy()
 
     def close(self):
         if getattr(self, "_h", None):

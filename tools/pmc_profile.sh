@@ -1,0 +1,34 @@
+#!/bin/bash
+# PMC passes for the trace kernel (run on the GPU box through gpurun).  Counters are collected in
+# their own runs (--pmc only, no tracing domains), one group per pass, as the microarch guide says.
+# usage: tools/pmc_profile.sh <outdir-under-gpurun_out> [bench args...]
+set -u
+OUT=/root/repo/gpurun_out/$1; shift
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+pass() {
+  name=$1; shift
+  rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-} > "$OUT/$name.json" 2> "$OUT/$name.err" || echo "pass $name failed rc=$?"
+}
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+pass ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
+pass sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_WR
+pass sq2 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU
+pass sq3 SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_WAVE_CYCLES
+pass grbm GRBM_GUI_ACTIVE
+rocprofv3 -L > "$OUT/counters_list.txt" 2>&1 || true
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections, json
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob(out + "/*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "trace_stack_kernel" in r["Kernel_Name"] or "trace_restart_kernel" in r["Kernel_Name"]:
+            a = agg[r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+res = {k: {"mean_per_launch": v[0] / v[1], "launches": v[1]} for k, v in sorted(agg.items())}
+json.dump(res, open(out + "/summary.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
