@@ -24,7 +24,8 @@ struct svo_ctx {
     bool top_dirty = true;
     uint32_t *top_table = nullptr;
     uint32_t *status = nullptr;        // device error word
-    uint32_t *work_counter = nullptr;  // device strip counter
+    uint32_t *defer_buf = nullptr;     // {strip counter, deferred count, deferred item indices...}
+    size_t defer_items = 0;
     // scan lists (compute.rs:46-64): slot 0 = count
     uint32_t *scan_sub = nullptr, *scan_unsub = nullptr;
     size_t scan_capacity = 0;
@@ -88,12 +89,17 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         rc = ensure_top_table(ctx);
         if (rc) return rc;
     }
+    svo::WorkDesc wd = work;
+    auto magic = [](uint32_t d) -> uint32_t { return d <= 1u ? 0u : (uint32_t)(0x100000000ull / d) + 1u; };
+    wd.magic_bpr = magic(wd.bpr);
+    wd.magic_bprect = magic(wd.bprect);
+    wd.magic_tiles_x = magic(wd.tiles_x);
     svo::TraceArgs a{};
     a.nodes = ctx->nodes;
     a.n_words = (uint32_t)ctx->capacity;
     a.top_table = ctx->top_table;
     a.u = ctx->uniforms;
-    a.work = work;
+    a.work = wd;
     a.rays = rays;
     a.hits = hits;
     a.rgba = rgba;
@@ -104,7 +110,18 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     li.grid_blocks = ctx->grid_blocks;
     li.num_cus = ctx->num_cus;
     li.strip_items = ctx->strip_items;
-    li.work_counter = ctx->dynamic_strips ? ctx->work_counter : nullptr;
+    if (ctx->variant == SVO_VARIANT_STACK && ctx->defer_items < wd.n_items) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->defer_buf) (void)hipFree(ctx->defer_buf);
+        ctx->defer_buf = nullptr;
+        ctx->defer_items = 0;
+        size_t want = wd.n_items < (1u << 16) ? (1u << 16) : wd.n_items;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->defer_buf, (want + 2) * sizeof(uint32_t)));
+        ctx->defer_items = want;
+    }
+    li.counters = ctx->defer_buf;
+    li.work_counter = ctx->dynamic_strips ? ctx->defer_buf : nullptr;
+    li.defer = ctx->defer_buf ? ctx->defer_buf + 1 : nullptr;
     const size_t slot = ctx->ev_slots ? (ctx->ev_count % ctx->ev_slots) : 0;
     if (ctx->ev_slots) HIP_TRY(ctx, hipEventRecord(ctx->ev[2 * slot], ctx->stream));
     HIP_TRY(ctx, svo::launch_trace(a, li, ctx->stream));
@@ -165,13 +182,12 @@ int svo_ctx_create(int hip_device, svo_ctx **out) {
         e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     }
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->top_table, svo::kTopEntries * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->status, 2 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(ctx->status, 0, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->status, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(ctx->status, 0, sizeof(uint32_t));
     if (e != hipSuccess) {
         svo_ctx_destroy(ctx);
         return SVO_ERR_HIP;
     }
-    ctx->work_counter = ctx->status + 1;
     ctx->stream = ctx->own_stream;
     *out = ctx;
     return SVO_OK;
@@ -184,6 +200,7 @@ int svo_ctx_destroy(svo_ctx *ctx) {
     if (ctx->nodes && ctx->nodes_owned) (void)hipFree(ctx->nodes);
     if (ctx->top_table) (void)hipFree(ctx->top_table);
     if (ctx->status) (void)hipFree(ctx->status);
+    if (ctx->defer_buf) (void)hipFree(ctx->defer_buf);
     if (ctx->scan_sub) (void)hipFree(ctx->scan_sub);
     if (ctx->scan_unsub) (void)hipFree(ctx->scan_unsub);
     if (ctx->stage) (void)hipFree(ctx->stage);
@@ -256,8 +273,8 @@ int svo_sync(svo_ctx *ctx) {
     if (st & 1u) {
         HIP_TRY(ctx, hipMemset(ctx->status, 0, sizeof(uint32_t)));
         return fail(ctx, SVO_ERR_STATE,
-                    "octree deeper than 24 levels met by the STACK variant (rays report the step-limit "
-                    "sentinel); use SVO_VARIANT_RESTART for such trees");
+                    "octree deeper than the STACK variant resolves (rays report the step-limit sentinel); "
+                    "use SVO_VARIANT_RESTART for such trees");
     }
     return SVO_OK;
 }

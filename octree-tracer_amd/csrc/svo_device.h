@@ -10,7 +10,7 @@ namespace svo {
 
 constexpr uint32_t kVoxelOffset = 134217728u;  // octree.rs:5
 constexpr uint32_t kMaxDescent = 31;           // descent guard (see oracle/svo_oracle.c)
-constexpr int kTopLevels = 4;                  // K: octree levels folded into the LDS top table
+constexpr int kTopLevels = 3;                  // K: octree levels folded into the LDS top table
 constexpr int kTopEntries = 1 << (3 * kTopLevels);
 constexpr int kPathBits = 24;                  // D: integer path-code bits per axis
 
@@ -33,6 +33,7 @@ struct WorkDesc {
     uint32_t tiles_x;     // mode 1: tiles per frame row
     uint32_t first_tile, tile_stride;
     uint32_t n_items;     // mode 0/1: n_rects * bprect * 64; mode 2: n_rays
+    uint32_t magic_bpr, magic_bprect, magic_tiles_x;  // floor(2^32 / d) + 1 (0 when d == 1), see fast_div
 };
 
 struct TraceArgs {
@@ -53,12 +54,15 @@ struct LaunchInfo {
     int grid_blocks;         // 0 = auto
     int num_cus;
     uint32_t strip_items;    // STACK: pixel slots a wave claims at a time (multiple of 64)
-    uint32_t *work_counter;  // STACK: device word for dynamic strip claiming, or nullptr (static round-robin)
+    uint32_t *counters;      // STACK: two device words zeroed per launch: {strip counter, deferred-ray count}
+    uint32_t *work_counter;  // STACK: counters + 0 for dynamic strip claiming, or nullptr (static round-robin)
+    uint32_t *defer;         // STACK: counters + 1 followed by one slot per item: rays handed to the RESTART kernel
 };
 
 hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint32_t *top_table,
                                   hipStream_t stream);
 hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream);
+int stack_max_depth();  // deepest tree level the STACK variant resolves
 hipError_t launch_scan(const uint32_t *nodes, uint32_t n_words, uint32_t node_length, uint32_t *sub,
                        uint32_t *unsub, uint32_t capacity, hipStream_t stream);
 

@@ -167,96 +167,102 @@ __device__ __forceinline__ RayIn item_ray(const TraceArgs &a, const Item &it) {
 // Variant RESTART: the reference's algorithm shape -- float-compare descent from the root on
 // every step (shader.wgsl:130-171 inside :213-245), one ray per lane, grid-stride over items.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void trace_restart_kernel(TraceArgs a) {
+__device__ __forceinline__ void trace_one_restart(const TraceArgs &a, rsrc_t rs, bool misc_bool, bool counter_hits,
+                                                  uint32_t q) {
+    Item it = decode_item(a.work, q);
+    if (!it.valid) return;
+    RayIn r = item_ray(a, it);
+    float pos[3], dir[3], dist;
+    if (!ray_enter(r, pos, dir, dist)) {
+        write_hit(a.hits, it.out, 0u, 0.0f, 0u, 0u, 0u, 0u);
+        return;
+    }
+    float rs0 = sign_w(dir[0]), rs1 = sign_w(dir[1]), rs2 = sign_w(dir[2]);
+    float vp0 = pos[0], vp1 = pos[1], vp2 = pos[2];
+    float n0 = truncf(pos[0] * 1.000001f), n1 = truncf(pos[1] * 1.000001f), n2 = truncf(pos[2] * 1.000001f);
+    uint32_t steps = 0;
+    float t_current = 0.0f;
+    for (;;) {
+        // find_voxel
+        uint32_t node_index = 0, depth = 0, p, word;
+        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+        bool overflow = false;
+        for (;;) {
+            depth += 1;
+            uint32_t bx, by, bz;
+            if (misc_bool) { bx = vp0 >= c0; by = vp1 >= c1; bz = vp2 >= c2; }
+            else           { bx = vp0 >  c0; by = vp1 >  c1; bz = vp2 >  c2; }
+            float d = (float)(1u << depth);
+            c0 = c0 + ((float)bx * 2.0f - 1.0f) / d;
+            c1 = c1 + ((float)by * 2.0f - 1.0f) / d;
+            c2 = c2 + ((float)bz * 2.0f - 1.0f) / d;
+            p = node_index + bx * 4u + by * 2u + bz;
+            word = load_word(rs, p);
+            uint32_t tn = word >> 4;
+            if (tn >= kVoxelOffset) break;
+            if (depth >= kMaxDescent) { overflow = true; break; }
+            node_index = tn;
+        }
+        uint32_t nc = normal_code(n0) | (normal_code(n1) << 2) | (normal_code(n2) << 4);
+        if (overflow) {
+            write_hit(a.hits, it.out, 0xFF000000u, dist + t_current, steps, 100u, 1u, nc);
+            return;
+        }
+        bool solid = counter_hits ? ((word & 15u) > 0u) : (((word >> 4) - kVoxelOffset) > 0u);
+        if (solid) {
+            write_hit(a.hits, it.out, p, dist + t_current, steps, depth, 1u, nc);
+            return;
+        }
+        float voxel_size = 2.0f / (float)(1u << depth);
+        float t0 = (c0 - pos[0] + rs0 * voxel_size / 2.0f) / dir[0];
+        float t1 = (c1 - pos[1] + rs1 * voxel_size / 2.0f) / dir[1];
+        float t2 = (c2 - pos[2] + rs2 * voxel_size / 2.0f) / dir[2];
+        float m0 = (t0 <= fmin_w(t1, t2)) ? 1.0f : 0.0f;
+        float m1 = (t1 <= fmin_w(t2, t0)) ? 1.0f : 0.0f;
+        float m2 = (t2 <= fmin_w(t0, t1)) ? 1.0f : 0.0f;
+        n0 = m0 * -rs0; n1 = m1 * -rs1; n2 = m2 * -rs2;
+        t_current = fmin_w(fmin_w(t0, t1), t2);
+        vp0 = pos[0] + dir[0] * t_current - n0 * 0.000002f;
+        vp1 = pos[1] + dir[1] * t_current - n1 * 0.000002f;
+        vp2 = pos[2] + dir[2] * t_current - n2 * 0.000002f;
+        if (!in_bounds(vp0, vp1, vp2)) {
+            write_hit(a.hits, it.out, 0x20202000u, dist + t_current, steps, depth, 0u, 0u);
+            return;
+        }
+        steps += 1;
+        if (steps > 100u) {
+            write_hit(a.hits, it.out, 0xFF000000u, dist + t_current, steps, 100u, 1u,
+                      normal_code(n0) | (normal_code(n1) << 2) | (normal_code(n2) << 4));
+            return;
+        }
+    }
+}
+
+// list == nullptr: every item of the work description; else the items list[1 .. list[0]] (rays the
+// STACK variant deferred because its fast arithmetic does not cover them).
+__global__ __launch_bounds__(256) void trace_restart_kernel(TraceArgs a, const uint32_t *list) {
     const rsrc_t rs = make_rsrc(a.nodes, a.n_words);
     const bool misc_bool = (a.u.flags & SVO_F_MISC_BOOL) != 0;
     const bool counter_hits = (a.u.flags & SVO_F_PAUSE_ADAPTIVE) && (a.u.flags & SVO_F_SHOW_HITS);
-    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < a.work.n_items; q += gridDim.x * 256u) {
-        Item it = decode_item(a.work, q);
-        if (!it.valid) continue;
-        RayIn r = item_ray(a, it);
-        float pos[3], dir[3], dist;
-        if (!ray_enter(r, pos, dir, dist)) {
-            write_hit(a.hits, it.out, 0u, 0.0f, 0u, 0u, 0u, 0u);
-            continue;
-        }
-        float rs0 = sign_w(dir[0]), rs1 = sign_w(dir[1]), rs2 = sign_w(dir[2]);
-        float vp0 = pos[0], vp1 = pos[1], vp2 = pos[2];
-        float n0 = truncf(pos[0] * 1.000001f), n1 = truncf(pos[1] * 1.000001f), n2 = truncf(pos[2] * 1.000001f);
-        uint32_t steps = 0;
-        float t_current = 0.0f;
-        for (;;) {
-            // find_voxel
-            uint32_t node_index = 0, depth = 0, p, word;
-            float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-            bool overflow = false;
-            for (;;) {
-                depth += 1;
-                uint32_t bx, by, bz;
-                if (misc_bool) { bx = vp0 >= c0; by = vp1 >= c1; bz = vp2 >= c2; }
-                else           { bx = vp0 >  c0; by = vp1 >  c1; bz = vp2 >  c2; }
-                float d = (float)(1u << depth);
-                c0 = c0 + ((float)bx * 2.0f - 1.0f) / d;
-                c1 = c1 + ((float)by * 2.0f - 1.0f) / d;
-                c2 = c2 + ((float)bz * 2.0f - 1.0f) / d;
-                p = node_index + bx * 4u + by * 2u + bz;
-                word = load_word(rs, p);
-                uint32_t tn = word >> 4;
-                if (tn >= kVoxelOffset) break;
-                if (depth >= kMaxDescent) { overflow = true; break; }
-                node_index = tn;
-            }
-            if (overflow) {
-                write_hit(a.hits, it.out, 0xFF000000u, dist + t_current, steps, 100u, 1u,
-                          normal_code(n0) | (normal_code(n1) << 2) | (normal_code(n2) << 4));
-                break;
-            }
-            bool solid = counter_hits ? ((word & 15u) > 0u) : (((word >> 4) - kVoxelOffset) > 0u);
-            if (solid) {
-                write_hit(a.hits, it.out, p, dist + t_current, steps, depth, 1u,
-                          normal_code(n0) | (normal_code(n1) << 2) | (normal_code(n2) << 4));
-                break;
-            }
-            float voxel_size = 2.0f / (float)(1u << depth);
-            float t0 = (c0 - pos[0] + rs0 * voxel_size / 2.0f) / dir[0];
-            float t1 = (c1 - pos[1] + rs1 * voxel_size / 2.0f) / dir[1];
-            float t2 = (c2 - pos[2] + rs2 * voxel_size / 2.0f) / dir[2];
-            float m0 = (t0 <= fmin_w(t1, t2)) ? 1.0f : 0.0f;
-            float m1 = (t1 <= fmin_w(t2, t0)) ? 1.0f : 0.0f;
-            float m2 = (t2 <= fmin_w(t0, t1)) ? 1.0f : 0.0f;
-            n0 = m0 * -rs0; n1 = m1 * -rs1; n2 = m2 * -rs2;
-            t_current = fmin_w(fmin_w(t0, t1), t2);
-            vp0 = pos[0] + dir[0] * t_current - n0 * 0.000002f;
-            vp1 = pos[1] + dir[1] * t_current - n1 * 0.000002f;
-            vp2 = pos[2] + dir[2] * t_current - n2 * 0.000002f;
-            if (!in_bounds(vp0, vp1, vp2)) {
-                write_hit(a.hits, it.out, 0x20202000u, dist + t_current, steps, depth, 0u, 0u);
-                break;
-            }
-            steps += 1;
-            if (steps > 100u) {
-                write_hit(a.hits, it.out, 0xFF000000u, dist + t_current, steps, 100u, 1u,
-                          normal_code(n0) | (normal_code(n1) << 2) | (normal_code(n2) << 4));
-                break;
-            }
-        }
-    }
+    const uint32_t n = list ? list[0] : a.work.n_items;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+        trace_one_restart(a, rs, misc_bool, counter_hits, list ? list[1u + i] : i);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Top table: fold the first kTopLevels levels into one word per level-K cell.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void build_top_table_kernel(const uint32_t *nodes, uint32_t n_words,
-                                                              uint32_t *table) {
+                                                              uint32_t *table, int top_levels) {
     const rsrc_t rs = make_rsrc(nodes, n_words);
     uint32_t cell = blockIdx.x * 256u + threadIdx.x;
-    if (cell >= (uint32_t)kTopEntries) return;
-    uint32_t cx = (cell >> (2 * kTopLevels)) & ((1u << kTopLevels) - 1u);
-    uint32_t cy = (cell >> kTopLevels) & ((1u << kTopLevels) - 1u);
-    uint32_t cz = cell & ((1u << kTopLevels) - 1u);
+    if (cell >= (1u << (3 * top_levels))) return;
+    uint32_t cx = (cell >> (2 * top_levels)) & ((1u << top_levels) - 1u);
+    uint32_t cy = (cell >> top_levels) & ((1u << top_levels) - 1u);
+    uint32_t cz = cell & ((1u << top_levels) - 1u);
     uint32_t node_index = 0, entry = 0;
-    for (int lvl = 1; lvl <= kTopLevels; lvl++) {
-        int sh = kTopLevels - lvl;
+    for (int lvl = 1; lvl <= top_levels; lvl++) {
+        int sh = top_levels - lvl;
         uint32_t child = (((cx >> sh) & 1u) << 2) | (((cy >> sh) & 1u) << 1) | ((cz >> sh) & 1u);
         uint32_t p = node_index + child;
         uint32_t tn = load_word(rs, p) >> 4;
@@ -273,6 +279,8 @@ __global__ __launch_bounds__(256) void build_top_table_kernel(const uint32_t *no
 // ---------------------------------------------------------------------------------------------
 // Variant STACK (see file header).
 // ---------------------------------------------------------------------------------------------
+// Path code of a position: bit (D - d) of the code is the child choice `pos > centre` (or `>=`)
+// at level d.  General form (any float, NaN included): used at ray entry.
 __device__ __forceinline__ int32_t path_code(float v, bool ge_mode) {
     // exact: v * 2^23 only moves the exponent; fmaxf/fminf (IEEE maxNum/minNum) send NaN to the bound,
     // which reproduces "every comparison false" (code 0)
@@ -284,25 +292,109 @@ __device__ __forceinline__ int32_t path_code(float v, bool ge_mode) {
     return i;
 }
 
-template <int BLOCK, int NS>
-__global__ __launch_bounds__(BLOCK) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
-                                                            uint32_t *work_counter) {
-    constexpr int K = kTopLevels;
+// Same for a position already known to lie in [-1, 1): no clamping of g needed.
+// ceil(g) - 1 == floor(g) - (g is an integer), so one floor serves both tie-break modes.
+__device__ __forceinline__ int32_t path_code_inb(float v, int32_t gt_adjust) {
+    float g = v * 8388608.0f;
+    float fl = floorf(g);
+    int32_t i = (int32_t)fl + 8388608 - ((fl == g) ? gt_adjust : 0);
+    return i < 0 ? 0 : i;
+}
+
+// n / d for n*d_err < 2^32 with one fix-up step; magic = floor(2^32 / d) + 1 (d >= 2), d == 1 handled by magic 0
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t d, uint32_t magic) {
+    if (magic == 0u) return n;
+    uint32_t q = __umulhi(n, magic);
+    uint32_t r = n - q * d;
+    return (r >= d) ? q - 1u : q;  // r wrapped below zero when q overshot by one
+}
+
+struct ItemFast {
+    bool valid;
+    uint32_t out, px, py;
+};
+
+__device__ __forceinline__ ItemFast decode_item_fast(const WorkDesc &w, uint32_t q) {
+    ItemFast it;
+    if (w.mode == 2) {
+        it.valid = q < w.n_items;
+        it.out = q;
+        it.px = it.py = 0;
+        return it;
+    }
+    uint32_t blk = q >> 6, lane = q & 63u;
+    uint32_t rect = 0, b = blk;
+    if (w.n_rects > 1u) {
+        rect = fast_div(blk, w.bprect, w.magic_bprect);
+        b = blk - rect * w.bprect;
+    }
+    uint32_t by = fast_div(b, w.bpr, w.magic_bpr), bx = b - by * w.bpr;
+    uint32_t x = bx * 8u + (lane & 7u), y = by * 8u + (lane >> 3);
+    it.valid = (q < w.n_items) && (x < w.w) && (y < w.h);
+    it.out = rect * (w.w * w.h) + y * w.w + x;
+    uint32_t ox = w.x0, oy = w.y0;
+    if (w.mode == 1) {
+        uint32_t t = w.first_tile + rect * w.tile_stride;
+        uint32_t ty = fast_div(t, w.tiles_x, w.magic_tiles_x);
+        ox = (t - ty * w.tiles_x) * w.w;
+        oy = ty * w.h;
+    }
+    it.px = ox + x;
+    it.py = oy + y;
+    return it;
+}
+
+// a / d given y = RN(1 / d): q0 = a*y is within 2 ulp of a/d; with the exact residuals r = a - d*q (fma)
+// each q + r*y correction squares the error, and by Markstein's theorem (y correctly rounded, q faithful)
+// the second correction returns the correctly rounded quotient -- the same bits as IEEE a / d.  Valid while
+// nothing over/underflows: the caller guarantees 2^-40 <= |d| <= 2^40 and a == 0 or 2^-53 <= |a| <= 2^21
+// (tools/divtest.c checks the sequence against a / d over those ranges).
+__device__ __forceinline__ float div_by_recip(float a, float d, float y) {
+    float q = a * y;
+    float r = __builtin_fmaf(-d, q, a);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-d, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+
+__device__ __forceinline__ float copysign_bits(float mag, float sgn) {
+    return __uint_as_float((__float_as_uint(mag) & 0x7FFFFFFFu) | (__float_as_uint(sgn) & 0x80000000u));
+}
+
+// "clean" ray: every quantity of the stepping arithmetic stays finite and inside the ranges the fast
+// forms above are proven for.  pos is the entry point (|pos| <= 2 always holds for rays that enter).
+__device__ __forceinline__ bool clean_component(float p, float d) {
+    float ap = fabsf(p), ad = fabsf(d);
+    bool p_ok = (ap <= 2.0f) && (p == 0.0f || ap >= 9.313225746154785e-10f);  // 2^-30
+    bool d_ok = (ad >= 9.094947017729282e-13f) && (ad <= 1099511627776.0f);     // 2^-40 .. 2^40
+    return p_ok && d_ok;  // NaN fails both
+}
+
+// Per-lane state word: bits 0..7 steps | 8..12 leaf depth L | 13..15 step mask (axes of the last step's
+// normal) | 16 normal-is-entry-normal | 19 active | 20 needs descent
+constexpr uint32_t ST_L_SHIFT = 8, ST_M_SHIFT = 13;
+constexpr uint32_t ST_ENTRY = 1u << 16, ST_ACTIVE = 1u << 19, ST_DESC = 1u << 20;
+constexpr uint32_t ST_L_MASK = 31u << ST_L_SHIFT, ST_M_MASK = 7u << ST_M_SHIFT;
+
+template <int BLOCK, int NS, int K, bool GE>
+__global__ __launch_bounds__(BLOCK, 8) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
+                                                               uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
-    constexpr int SMAX = K + 1 + NS;   // last level kept on the LDS stack
+    constexpr int SMAX = K + 1 + NS;   // last level kept on the LDS stack = deepest level resolved
+    static_assert(SMAX <= D, "stack deeper than the path codes");
+    constexpr int TBL = 1 << (3 * K);
     extern __shared__ uint32_t lds[];
-    uint32_t *tbl = lds;                 // kTopEntries
-    uint32_t *stk = lds + kTopEntries;   // [NS][BLOCK]
+    uint32_t *tbl = lds;          // TBL entries
+    uint32_t *stk = lds + TBL;    // [NS][BLOCK]
 
     const uint32_t tid = threadIdx.x;
     const rsrc_t rs = make_rsrc(a.nodes, a.n_words);
-    const bool ge_mode = (a.u.flags & SVO_F_MISC_BOOL) != 0;
     const bool counter_hits = (a.u.flags & SVO_F_PAUSE_ADAPTIVE) && (a.u.flags & SVO_F_SHOW_HITS);
     const bool use_table = (a.top_table != nullptr) && !counter_hits;
 
     if (use_table)
-        for (uint32_t i = tid; i < (uint32_t)kTopEntries; i += BLOCK) tbl[i] = a.top_table[i];
+        for (uint32_t i = tid; i < (uint32_t)TBL; i += BLOCK) tbl[i] = a.top_table[i];
     __syncthreads();
 
     const uint32_t n_items = a.work.n_items;
@@ -327,47 +419,61 @@ __global__ __launch_bounds__(BLOCK) void trace_stack_kernel(TraceArgs a, uint32_
     }
 
     // per-lane ray state
-    bool active = false;
-    uint32_t out = 0;
-    float pos[3] = {0, 0, 0}, dir[3] = {1, 1, 1};
+    uint32_t st = 0;                  // packed, see ST_*
+    uint32_t out = 0, entry_ncode = 0;
+    float pos0 = 0, pos1 = 0, pos2 = 0, dir0 = 1, dir1 = 1, dir2 = 1, y0 = 1, y1 = 1, y2 = 1;
     float dist = 0.0f, tcur = 0.0f;
     int32_t ix = 0, iy = 0, iz = 0;
-    uint32_t steps = 0, ncode = 0;
     uint32_t lvl = 1, nidx = 0;       // next level to read and the child group it lives in
-    uint32_t leaf_p = 0, L = 0;       // current leaf: word index and depth
-    bool solid = false, desc = false;
+    uint32_t leaf_p = 0, leaf_w = 0;  // current leaf: word index and word
+
+    // leaf words standing in for table hits (only solidity is read from them)
+    constexpr uint32_t kEmptyLeaf = kVoxelOffset << 4, kSolidLeaf = (kVoxelOffset + 1u) << 4;
 
     for (;;) {
         // ---- 1. refill idle lanes (ballot compaction) ----
-        uint64_t act = __ballot(active);
+        uint64_t act = __ballot((st & ST_ACTIVE) != 0u);
         if (next != 0xFFFFFFFFu) {
             uint32_t n_idle = 64u - (uint32_t)__popcll(act);
             if (n_idle >= a.refill_min || act == 0ull) {
                 uint32_t avail = strip_end - next;
-                if (!active) {
+                if (!(st & ST_ACTIVE)) {
                     uint64_t idle = ~act;
                     uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                     if (rank < avail) {
-                        Item it = decode_item(a.work, next + rank);
+                        const uint32_t q = next + rank;
+                        ItemFast it = decode_item_fast(a.work, q);
                         if (it.valid) {
-                            RayIn r = item_ray(a, it);
+                            RayIn r;
+                            if (a.work.mode == 2) {
+                                const float *p = a.rays + 6ull * it.out;
+                                r = RayIn{p[0], p[1], p[2], p[3], p[4], p[5]};
+                            } else {
+                                r = gen_ray(a.u, it.px, it.py);
+                            }
                             out = it.out;
+                            float pos[3], dir[3];
                             if (!ray_enter(r, pos, dir, dist)) {
                                 write_hit(a.hits, out, 0u, 0.0f, 0u, 0u, 0u, 0u);
+                            } else if (!(clean_component(pos[0], dir[0]) && clean_component(pos[1], dir[1]) &&
+                                         clean_component(pos[2], dir[2]) && fabsf(dist) <= 1.0e30f)) {
+                                // outside the proven range of the fast arithmetic: hand the ray to the
+                                // reference-shaped kernel that runs right after this one
+                                uint32_t slot = atomicAdd(&defer[0], 1u);
+                                defer[1u + slot] = q;
                             } else {
-                                active = true;
-                                steps = 0;
+                                pos0 = pos[0]; pos1 = pos[1]; pos2 = pos[2];
+                                dir0 = dir[0]; dir1 = dir[1]; dir2 = dir[2];
+                                y0 = 1.0f / dir0; y1 = 1.0f / dir1; y2 = 1.0f / dir2;
                                 tcur = 0.0f;
-                                ncode = normal_code(truncf(pos[0] * 1.000001f)) |
-                                        (normal_code(truncf(pos[1] * 1.000001f)) << 2) |
-                                        (normal_code(truncf(pos[2] * 1.000001f)) << 4);
-                                ix = path_code(pos[0], ge_mode);
-                                iy = path_code(pos[1], ge_mode);
-                                iz = path_code(pos[2], ge_mode);
-                                L = 0;
-                                // start from the top
-                                desc = true;
+                                entry_ncode = normal_code(truncf(pos0 * 1.000001f)) |
+                                              (normal_code(truncf(pos1 * 1.000001f)) << 2) |
+                                              (normal_code(truncf(pos2 * 1.000001f)) << 4);
+                                ix = path_code(pos0, GE);
+                                iy = path_code(pos1, GE);
+                                iz = path_code(pos2, GE);
+                                st = ST_ACTIVE | ST_DESC | ST_ENTRY;  // steps = 0, L = 0
                                 lvl = 1;
                                 nidx = 0;
                                 if (use_table) {
@@ -375,10 +481,9 @@ __global__ __launch_bounds__(BLOCK) void trace_stack_kernel(TraceArgs a, uint32_
                                                     ((uint32_t)(iy >> (D - K)) << K) | (uint32_t)(iz >> (D - K));
                                     uint32_t e = tbl[cell];
                                     if (e & kTopLeaf) {
-                                        desc = false;
                                         leaf_p = e & 0x07FFFFFFu;
-                                        L = (e >> 27) & 7u;
-                                        solid = (e & kTopSolid) != 0u;
+                                        leaf_w = (e & kTopSolid) ? kSolidLeaf : kEmptyLeaf;
+                                        st = ST_ACTIVE | ST_ENTRY | (((e >> 27) & 7u) << ST_L_SHIFT);
                                     } else {
                                         lvl = K + 1;
                                         nidx = e;
@@ -405,7 +510,7 @@ __global__ __launch_bounds__(BLOCK) void trace_stack_kernel(TraceArgs a, uint32_
                         next = strip_end = 0xFFFFFFFFu;
                     }
                 }
-                act = __ballot(active);
+                act = __ballot((st & ST_ACTIVE) != 0u);
                 if (act == 0ull) {
                     if (next == 0xFFFFFFFFu) break;
                     continue;
@@ -416,97 +521,114 @@ __global__ __launch_bounds__(BLOCK) void trace_stack_kernel(TraceArgs a, uint32_
         }
 
         // ---- 2. descent: one dependent word per level below the restart level ----
-        bool overflow = false;
-        while (desc) {
-            int sh = D - (int)lvl;
-            uint32_t child = ((((uint32_t)ix >> sh) & 1u) << 2) | ((((uint32_t)iy >> sh) & 1u) << 1) |
-                             (((uint32_t)iz >> sh) & 1u);
-            uint32_t p = nidx + child;
-            uint32_t w = load_word(rs, p);
-            uint32_t tn = w >> 4;
-            if (tn >= kVoxelOffset) {
-                leaf_p = p;
-                L = lvl;
-                solid = counter_hits ? ((w & 15u) > 0u) : (tn != kVoxelOffset);
-                desc = false;
-            } else if (lvl >= (uint32_t)D) {
-                overflow = true;  // deeper than the integer path codes resolve
-                desc = false;
-            } else {
+        if (st & ST_DESC) {
+            uint32_t p, w;
+            uint32_t sp = (lvl > (uint32_t)SBASE - 1u ? lvl - ((uint32_t)SBASE - 1u) : 0u) * BLOCK + tid;  // slot of level lvl+1
+            for (;;) {
+                uint32_t sh = (uint32_t)D - lvl;
+                uint32_t child = (__builtin_amdgcn_ubfe((uint32_t)ix, sh, 1u) << 2) |
+                                 (__builtin_amdgcn_ubfe((uint32_t)iy, sh, 1u) << 1) |
+                                 __builtin_amdgcn_ubfe((uint32_t)iz, sh, 1u);
+                p = nidx + child;
+                w = load_word(rs, p);
+                // leaf (pointer >= VOXEL_OFFSET <=> word >= VOXEL_OFFSET << 4), or deeper than SMAX (refused)
+                if (w >= (kVoxelOffset << 4) || lvl >= (uint32_t)SMAX) break;
                 lvl += 1;
-                nidx = tn;
-                if (lvl >= (uint32_t)SBASE && lvl <= (uint32_t)SMAX) stk[(lvl - SBASE) * BLOCK + tid] = tn;
+                nidx = w >> 4;
+                stk[sp] = nidx;  // without the table levels below SBASE all land in slot 0, rewritten at SBASE
+                sp += (lvl >= (uint32_t)SBASE) ? BLOCK : 0u;
             }
+            leaf_p = p;
+            leaf_w = w;
+            st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
         }
 
-        // ---- 3. hit test / DDA step (shader.wgsl:215-244) ----
-        if (active) {
-            if (overflow) {
-                atomicOr(a.status, 1u);
-                write_hit(a.hits, out, 0xFF000000u, dist + tcur, steps, 100u, 1u, ncode);
-                active = false;
-            } else if (solid) {
-                write_hit(a.hits, out, leaf_p, dist + tcur, steps, L, 1u, ncode);
-                active = false;
+        // ---- 3. hit test / DDA step (shader.wgsl:215-244), clean rays only ----
+        if (st & ST_ACTIVE) {
+            const uint32_t L = (st >> ST_L_SHIFT) & 31u;
+            const bool too_deep = leaf_w < (kVoxelOffset << 4);  // descent stopped on an interior word
+            const bool solid = counter_hits ? ((leaf_w & 15u) > 0u) : ((leaf_w >> 4) != kVoxelOffset);
+            // leaf centre from the path code: exact, equals the reference's accumulated node_pos
+            const uint32_t sh = (uint32_t)D - L;
+            const float inv = __uint_as_float((127u - L) << 23);  // 2^-L = voxel_size / 2
+            const int32_t bias = 1 - (1 << L);
+            const float c0 = (float)(((ix >> sh) << 1) + bias) * inv;
+            const float c1 = (float)(((iy >> sh) << 1) + bias) * inv;
+            const float c2 = (float)(((iz >> sh) << 1) + bias) * inv;
+            // r_sign * voxel_size / 2 = copysign(2^-L, dir): dir is never 0 or NaN on a clean ray
+            const float t0 = div_by_recip((c0 - pos0) + copysign_bits(inv, dir0), dir0, y0);
+            const float t1 = div_by_recip((c1 - pos1) + copysign_bits(inv, dir1), dir1, y1);
+            const float t2 = div_by_recip((c2 - pos2) + copysign_bits(inv, dir2), dir2, y2);
+            // no NaNs here, so IEEE minNum equals the oracle's (b < a) ? b : a up to the sign of a zero,
+            // which no later value depends on
+            const float t12 = __builtin_fminf(t1, t2), t20 = __builtin_fminf(t2, t0), t01 = __builtin_fminf(t0, t1);
+            const bool m0 = t0 <= t12, m1 = t1 <= t20, m2 = t2 <= t01;
+            const float tnew = __builtin_fminf(t01, t2);
+            // voxel_pos = pos + dir * t - normal * 2e-6, normal = mask * -sign(dir): subtracting -k is adding k
+            float vp0 = pos0 + dir0 * tnew, vp1 = pos1 + dir1 * tnew, vp2 = pos2 + dir2 * tnew;
+            vp0 = m0 ? vp0 + copysign_bits(0.000002f, dir0) : vp0;
+            vp1 = m1 ? vp1 + copysign_bits(0.000002f, dir1) : vp1;
+            vp2 = m2 ? vp2 + copysign_bits(0.000002f, dir2) : vp2;
+            const bool inb = (__builtin_fmaxf(__builtin_fmaxf(vp0, vp1), vp2) < 1.0f) &&
+                             (__builtin_fminf(__builtin_fminf(vp0, vp1), vp2) >= -1.0f);
+            const bool stop_here = too_deep || solid;         // finish before stepping
+            const uint32_t steps_new = (st & 0xFFu) + 1u;
+            const bool capped = steps_new > 100u;
+            const bool fin = stop_here || !inb || capped;
+            if (fin) {
+                if (too_deep) atomicOr(a.status, 1u);
+                const uint32_t mbits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u);
+                // normal of the record: the step just taken (capped), the previous one (solid / too deep) or none (left the cube)
+                uint32_t nm = stop_here ? ((st >> ST_M_SHIFT) & 7u) : mbits;
+                uint32_t c0n = (dir0 > 0.0f) ? 2u : 1u, c1n = (dir1 > 0.0f) ? 2u : 1u, c2n = (dir2 > 0.0f) ? 2u : 1u;
+                uint32_t ncode = ((nm & 1u) ? c0n : 0u) | ((nm & 2u) ? (c1n << 2) : 0u) | ((nm & 4u) ? (c2n << 4) : 0u);
+                if (stop_here && (st & ST_ENTRY)) ncode = entry_ncode;
+                uint32_t value = too_deep ? 0xFF000000u : (solid ? leaf_p : (!inb ? 0x20202000u : 0xFF000000u));
+                uint32_t depth = (too_deep || (!solid && inb)) ? 100u : L;
+                uint32_t hit = (stop_here || inb) ? 1u : 0u;
+                if (!stop_here && !inb) ncode = 0u;  // the miss record carries no normal
+                write_hit(a.hits, out, value, dist + (stop_here ? tcur : tnew), stop_here ? (st & 0xFFu) : (inb ? steps_new : (st & 0xFFu)),
+                          depth, hit, ncode);
+                st = 0u;
             } else {
-                // leaf centre from the path code: exact, equals the reference's accumulated node_pos
-                int sh = D - (int)L;
-                float inv = __uint_as_float((127u - L) << 23);  // 2^-L
-                int32_t half = 1 << L;
-                float c0 = (float)(2 * (ix >> sh) + 1 - half) * inv;
-                float c1 = (float)(2 * (iy >> sh) + 1 - half) * inv;
-                float c2 = (float)(2 * (iz >> sh) + 1 - half) * inv;
-                float rs0 = sign_w(dir[0]), rs1 = sign_w(dir[1]), rs2 = sign_w(dir[2]);
-                float voxel_size = inv * 2.0f;  // 2 / 2^L, exact
-                float t0 = (c0 - pos[0] + rs0 * voxel_size / 2.0f) / dir[0];
-                float t1 = (c1 - pos[1] + rs1 * voxel_size / 2.0f) / dir[1];
-                float t2 = (c2 - pos[2] + rs2 * voxel_size / 2.0f) / dir[2];
-                float m0 = (t0 <= fmin_w(t1, t2)) ? 1.0f : 0.0f;
-                float m1 = (t1 <= fmin_w(t2, t0)) ? 1.0f : 0.0f;
-                float m2 = (t2 <= fmin_w(t0, t1)) ? 1.0f : 0.0f;
-                float n0 = m0 * -rs0, n1 = m1 * -rs1, n2 = m2 * -rs2;
-                tcur = fmin_w(fmin_w(t0, t1), t2);
-                float vp0 = pos[0] + dir[0] * tcur - n0 * 0.000002f;
-                float vp1 = pos[1] + dir[1] * tcur - n1 * 0.000002f;
-                float vp2 = pos[2] + dir[2] * tcur - n2 * 0.000002f;
-                ncode = normal_code(n0) | (normal_code(n1) << 2) | (normal_code(n2) << 4);
-                if (!in_bounds(vp0, vp1, vp2)) {
-                    write_hit(a.hits, out, 0x20202000u, dist + tcur, steps, L, 0u, 0u);
-                    active = false;
+                tcur = tnew;
+                const uint32_t mbits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u);
+                st = ((st & ~(ST_M_MASK | ST_ENTRY | 0xFFu)) | (mbits << ST_M_SHIFT) | steps_new) | ST_DESC;
+                // new path codes: the position is inside [-1, 1), so no clamping of g
+                int32_t jx, jy, jz;
+                if (GE) {
+                    jx = (int32_t)floorf(vp0 * 8388608.0f) + 8388608;
+                    jy = (int32_t)floorf(vp1 * 8388608.0f) + 8388608;
+                    jz = (int32_t)floorf(vp2 * 8388608.0f) + 8388608;
                 } else {
-                    steps += 1;
-                    if (steps > 100u) {
-                        write_hit(a.hits, out, 0xFF000000u, dist + tcur, steps, 100u, 1u, ncode);
-                        active = false;
-                    } else {
-                        int32_t jx = path_code(vp0, ge_mode), jy = path_code(vp1, ge_mode), jz = path_code(vp2, ge_mode);
-                        uint32_t diff = (uint32_t)((ix ^ jx) | (iy ^ jy) | (iz ^ jz));
-                        uint32_t c = diff ? ((uint32_t)__clz((int)diff) - (32u - D)) : (uint32_t)D;  // shared levels
-                        ix = jx; iy = jy; iz = jz;
-                        uint32_t r = min(min(c + 1u, L), (uint32_t)SMAX);
-                        desc = true;
-                        if (r <= (uint32_t)(K + 1)) {
-                            lvl = 1;
-                            nidx = 0;
-                            if (use_table) {
-                                uint32_t cell = ((uint32_t)(ix >> (D - K)) << (2 * K)) |
-                                                ((uint32_t)(iy >> (D - K)) << K) | (uint32_t)(iz >> (D - K));
-                                uint32_t e = tbl[cell];
-                                if (e & kTopLeaf) {
-                                    desc = false;
-                                    leaf_p = e & 0x07FFFFFFu;
-                                    L = (e >> 27) & 7u;
-                                    solid = (e & kTopSolid) != 0u;
-                                } else {
-                                    lvl = K + 1;
-                                    nidx = e;
-                                }
-                            }
+                    jx = max((int32_t)ceilf(vp0 * 8388608.0f) + 8388607, 0);
+                    jy = max((int32_t)ceilf(vp1 * 8388608.0f) + 8388607, 0);
+                    jz = max((int32_t)ceilf(vp2 * 8388608.0f) + 8388607, 0);
+                }
+                const uint32_t diff = (uint32_t)((ix ^ jx) | (iy ^ jy) | (iz ^ jz));
+                // levels shared by the old and new path: clz over the 24-bit codes (diff == 0: all 24)
+                const uint32_t c = (uint32_t)__clz((int)((diff << 8) | 0x80u));
+                ix = jx; iy = jy; iz = jz;
+                const uint32_t r = min(min(c + 1u, L), (uint32_t)SMAX);
+                if (r <= (uint32_t)(K + 1)) {
+                    lvl = 1;
+                    nidx = 0;
+                    if (use_table) {
+                        uint32_t cell = ((uint32_t)(ix >> (D - K)) << (2 * K)) | ((uint32_t)(iy >> (D - K)) << K) |
+                                        (uint32_t)(iz >> (D - K));
+                        uint32_t e = tbl[cell];
+                        if (e & kTopLeaf) {
+                            leaf_p = e & 0x07FFFFFFu;
+                            leaf_w = (e & kTopSolid) ? kSolidLeaf : kEmptyLeaf;
+                            st = (st & ~(ST_L_MASK | ST_DESC)) | (((e >> 27) & 7u) << ST_L_SHIFT);
                         } else {
-                            lvl = r;
-                            nidx = stk[(r - SBASE) * BLOCK + tid];
+                            lvl = K + 1;
+                            nidx = e;
                         }
                     }
+                } else {
+                    lvl = r;
+                    nidx = stk[(r - SBASE) * BLOCK + tid];
                 }
             }
         }
@@ -549,27 +671,22 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t *nodes, uint32
 // launchers
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint32_t *top_table, hipStream_t stream) {
-    hipLaunchKernelGGL(build_top_table_kernel, dim3(kTopEntries / 256), dim3(256), 0, stream, nodes, n_words, top_table);
+    const int cells = 1 << (3 * kTopLevels);
+    hipLaunchKernelGGL(build_top_table_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream, nodes, n_words,
+                       top_table, kTopLevels);
     return hipGetLastError();
 }
 
 constexpr int kStackBlock = 256;
 constexpr int kStackLevels = 16;
 
-hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
+int stack_max_depth() { return kTopLevels + 1 + kStackLevels; }
+
+template <bool GE>
+static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
     const uint32_t strip_items = li.strip_items ? li.strip_items : 64u;
-    uint32_t *work_counter = li.work_counter;
-    if (args.work.n_items == 0) return hipSuccess;
-    if (li.variant == SVO_VARIANT_RESTART) {
-        uint32_t blocks = (args.work.n_items + 255u) / 256u;
-        uint32_t cap = (uint32_t)li.num_cus * 8u;
-        if (li.grid_blocks > 0) cap = (uint32_t)li.grid_blocks;
-        if (blocks > cap) blocks = cap;
-        hipLaunchKernelGGL(trace_restart_kernel, dim3(blocks), dim3(256), 0, stream, args);
-        return hipGetLastError();
-    }
-    auto kern = trace_stack_kernel<kStackBlock, kStackLevels>;
-    size_t lds_bytes = (size_t)(kTopEntries + kStackLevels * kStackBlock) * sizeof(uint32_t);
+    auto kern = trace_stack_kernel<kStackBlock, kStackLevels, kTopLevels, GE>;
+    size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + kStackLevels * kStackBlock) * sizeof(uint32_t);
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
         int n = 0;
@@ -582,11 +699,28 @@ hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t
     uint32_t n_strips = (args.work.n_items + strip_items - 1) / strip_items;
     uint32_t need = (n_strips + (kStackBlock / 64) - 1) / (kStackBlock / 64);
     if (blocks > need) blocks = need;
-    if (work_counter) {
-        hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
-        if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kStackBlock), lds_bytes, stream, args, strip_items, li.work_counter,
+                       li.defer);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
+    if (args.work.n_items == 0) return hipSuccess;
+    if (li.variant == SVO_VARIANT_RESTART) {
+        uint32_t blocks = (args.work.n_items + 255u) / 256u;
+        uint32_t cap = (uint32_t)li.num_cus * 8u;
+        if (li.grid_blocks > 0) cap = (uint32_t)li.grid_blocks;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(trace_restart_kernel, dim3(blocks), dim3(256), 0, stream, args, (const uint32_t *)nullptr);
+        return hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kStackBlock), lds_bytes, stream, args, strip_items, work_counter);
+    // li.counters = {strip counter, deferred-ray count}: zeroed together ahead of the launch
+    hipError_t e = hipMemsetAsync(li.counters, 0, 2 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    e = (args.u.flags & SVO_F_MISC_BOOL) ? launch_stack<true>(args, li, stream) : launch_stack<false>(args, li, stream);
+    if (e != hipSuccess) return e;
+    // rays outside the fast arithmetic's proven range (NaN / inf / extreme magnitudes): reference-shaped kernel
+    hipLaunchKernelGGL(trace_restart_kernel, dim3(16), dim3(256), 0, stream, args, (const uint32_t *)li.defer);
     return hipGetLastError();
 }
 
