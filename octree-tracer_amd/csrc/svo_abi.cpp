@@ -37,8 +37,8 @@ struct svo_ctx {
     // options
     int variant = SVO_VARIANT_STACK;
     int grid_blocks = 0;
-    uint32_t refill_min = 16;
-    uint32_t strip_items = 64;
+    uint32_t refill_min = 8;
+    uint32_t strip_items = 128;
     bool dynamic_strips = true;
     // launch timing: a ring of (start, stop) event pairs recorded around trace launches
     std::vector<hipEvent_t> ev;  // 2 per slot

@@ -376,8 +376,14 @@ constexpr uint32_t ST_L_SHIFT = 8, ST_M_SHIFT = 13;
 constexpr uint32_t ST_ENTRY = 1u << 16, ST_ACTIVE = 1u << 19, ST_DESC = 1u << 20;
 constexpr uint32_t ST_L_MASK = 31u << ST_L_SHIFT, ST_M_MASK = 7u << ST_M_SHIFT;
 
+// Ray pool: a wave generates the rays of up to 64 work items at once, with every lane busy (lanes that
+// are still traversing compute a ray for somebody else), compacts the ones that enter the cube into LDS,
+// and idle lanes later pick them up.  Ray generation (2 mat-vecs, 11 divisions, a square root) is thereby
+// paid once per 64 rays at full lane utilisation instead of on every refill.
+constexpr int kPoolWords = 8;  // pos.xyz, dir.xyz (biased), dist, out | entry normal code << 26
+
 template <int BLOCK, int NS, int K, bool GE>
-__global__ __launch_bounds__(BLOCK, 8) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
+__global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
@@ -385,10 +391,13 @@ __global__ __launch_bounds__(BLOCK, 8) void trace_stack_kernel(TraceArgs a, uint
     static_assert(SMAX <= D, "stack deeper than the path codes");
     constexpr int TBL = 1 << (3 * K);
     extern __shared__ uint32_t lds[];
-    uint32_t *tbl = lds;          // TBL entries
-    uint32_t *stk = lds + TBL;    // [NS][BLOCK]
+    uint32_t *tbl = lds;                          // TBL entries
+    uint32_t *stk = lds + TBL;                    // [NS][BLOCK]
+    uint32_t *pool_all = stk + NS * BLOCK;        // [BLOCK / 64][kPoolWords][64]
 
     const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    uint32_t *pool = pool_all + (tid >> 6) * (kPoolWords * 64);
     const rsrc_t rs = make_rsrc(a.nodes, a.n_words);
     const bool counter_hits = (a.u.flags & SVO_F_PAUSE_ADAPTIVE) && (a.u.flags & SVO_F_SHOW_HITS);
     const bool use_table = (a.top_table != nullptr) && !counter_hits;
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(BLOCK, 8) void trace_stack_kernel(TraceArgs a, uint
     uint32_t strip, next, strip_end;
     if (work_counter) {
         uint32_t s = 0;
-        if ((tid & 63u) == 0) s = atomicAdd(work_counter, 1u);
+        if (lane == 0) s = atomicAdd(work_counter, 1u);
         strip = __builtin_amdgcn_readfirstlane(s);
     } else {
         strip = wave_id;
@@ -417,10 +426,11 @@ __global__ __launch_bounds__(BLOCK, 8) void trace_stack_kernel(TraceArgs a, uint
     } else {
         next = strip_end = 0xFFFFFFFFu;
     }
+    uint32_t pool_n = 0, pool_i = 0;  // wave-uniform: rays waiting in the pool, index of the first
 
     // per-lane ray state
     uint32_t st = 0;                  // packed, see ST_*
-    uint32_t out = 0, entry_ncode = 0;
+    uint32_t out = 0;                 // bits 0..25 output index, 26..31 entry normal code
     float pos0 = 0, pos1 = 0, pos2 = 0, dir0 = 1, dir1 = 1, dir2 = 1, y0 = 1, y1 = 1, y2 = 1;
     float dist = 0.0f, tcur = 0.0f;
     int32_t ix = 0, iy = 0, iz = 0;
@@ -431,18 +441,19 @@ __global__ __launch_bounds__(BLOCK, 8) void trace_stack_kernel(TraceArgs a, uint
     constexpr uint32_t kEmptyLeaf = kVoxelOffset << 4, kSolidLeaf = (kVoxelOffset + 1u) << 4;
 
     for (;;) {
-        // ---- 1. refill idle lanes (ballot compaction) ----
+        // ---- 1. refill idle lanes from the ray pool (ballot compaction) ----
         uint64_t act = __ballot((st & ST_ACTIVE) != 0u);
-        if (next != 0xFFFFFFFFu) {
+        const bool more = (pool_n != 0u) || (next != 0xFFFFFFFFu);
+        if (more) {
             uint32_t n_idle = 64u - (uint32_t)__popcll(act);
             if (n_idle >= a.refill_min || act == 0ull) {
-                uint32_t avail = strip_end - next;
-                if (!(st & ST_ACTIVE)) {
-                    uint64_t idle = ~act;
-                    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
-                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                    if (rank < avail) {
-                        const uint32_t q = next + rank;
+                if (pool_n == 0u) {
+                    // -- generate the next (up to) 64 rays, all lanes --
+                    const uint32_t q = next + lane;
+                    bool alive = false;
+                    float gp0 = 0, gp1 = 0, gp2 = 0, gd0 = 0, gd1 = 0, gd2 = 0, gdist = 0;
+                    uint32_t gout = 0;
+                    if (q < strip_end) {
                         ItemFast it = decode_item_fast(a.work, q);
                         if (it.valid) {
                             RayIn r;
@@ -452,67 +463,102 @@ __global__ __launch_bounds__(BLOCK, 8) void trace_stack_kernel(TraceArgs a, uint
                             } else {
                                 r = gen_ray(a.u, it.px, it.py);
                             }
-                            out = it.out;
                             float pos[3], dir[3];
-                            if (!ray_enter(r, pos, dir, dist)) {
-                                write_hit(a.hits, out, 0u, 0.0f, 0u, 0u, 0u, 0u);
+                            if (!ray_enter(r, pos, dir, gdist)) {
+                                write_hit(a.hits, it.out, 0u, 0.0f, 0u, 0u, 0u, 0u);
                             } else if (!(clean_component(pos[0], dir[0]) && clean_component(pos[1], dir[1]) &&
-                                         clean_component(pos[2], dir[2]) && fabsf(dist) <= 1.0e30f)) {
+                                         clean_component(pos[2], dir[2]) && fabsf(gdist) <= 1.0e30f)) {
                                 // outside the proven range of the fast arithmetic: hand the ray to the
                                 // reference-shaped kernel that runs right after this one
                                 uint32_t slot = atomicAdd(&defer[0], 1u);
                                 defer[1u + slot] = q;
                             } else {
-                                pos0 = pos[0]; pos1 = pos[1]; pos2 = pos[2];
-                                dir0 = dir[0]; dir1 = dir[1]; dir2 = dir[2];
-                                y0 = 1.0f / dir0; y1 = 1.0f / dir1; y2 = 1.0f / dir2;
-                                tcur = 0.0f;
-                                entry_ncode = normal_code(truncf(pos0 * 1.000001f)) |
-                                              (normal_code(truncf(pos1 * 1.000001f)) << 2) |
-                                              (normal_code(truncf(pos2 * 1.000001f)) << 4);
-                                ix = path_code(pos0, GE);
-                                iy = path_code(pos1, GE);
-                                iz = path_code(pos2, GE);
-                                st = ST_ACTIVE | ST_DESC | ST_ENTRY;  // steps = 0, L = 0
-                                lvl = 1;
-                                nidx = 0;
-                                if (use_table) {
-                                    uint32_t cell = ((uint32_t)(ix >> (D - K)) << (2 * K)) |
-                                                    ((uint32_t)(iy >> (D - K)) << K) | (uint32_t)(iz >> (D - K));
-                                    uint32_t e = tbl[cell];
-                                    if (e & kTopLeaf) {
-                                        leaf_p = e & 0x07FFFFFFu;
-                                        leaf_w = (e & kTopSolid) ? kSolidLeaf : kEmptyLeaf;
-                                        st = ST_ACTIVE | ST_ENTRY | (((e >> 27) & 7u) << ST_L_SHIFT);
-                                    } else {
-                                        lvl = K + 1;
-                                        nidx = e;
-                                    }
-                                }
+                                alive = true;
+                                gp0 = pos[0]; gp1 = pos[1]; gp2 = pos[2];
+                                gd0 = dir[0]; gd1 = dir[1]; gd2 = dir[2];
+                                uint32_t ncode = normal_code(truncf(gp0 * 1.000001f)) |
+                                                 (normal_code(truncf(gp1 * 1.000001f)) << 2) |
+                                                 (normal_code(truncf(gp2 * 1.000001f)) << 4);
+                                gout = it.out | (ncode << 26);
+                            }
+                        }
+                    }
+                    const uint64_t am = __ballot(alive);
+                    if (alive) {
+                        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+                        pool[0 * 64 + slot] = __float_as_uint(gp0);
+                        pool[1 * 64 + slot] = __float_as_uint(gp1);
+                        pool[2 * 64 + slot] = __float_as_uint(gp2);
+                        pool[3 * 64 + slot] = __float_as_uint(gd0);
+                        pool[4 * 64 + slot] = __float_as_uint(gd1);
+                        pool[5 * 64 + slot] = __float_as_uint(gd2);
+                        pool[6 * 64 + slot] = __float_as_uint(gdist);
+                        pool[7 * 64 + slot] = gout;
+                    }
+                    pool_n = (uint32_t)__popcll(am);
+                    pool_i = 0u;
+                    next += min(64u, strip_end - next);
+                    if (next >= strip_end) {
+                        if (work_counter) {
+                            uint32_t s = 0;
+                            if (lane == 0) s = atomicAdd(work_counter, 1u);
+                            strip = __builtin_amdgcn_readfirstlane(s);
+                        } else {
+                            strip += n_waves;
+                        }
+                        if (strip < n_strips) {
+                            next = strip * strip_items;
+                            strip_end = min(next + strip_items, n_items);
+                        } else {
+                            next = strip_end = 0xFFFFFFFFu;
+                        }
+                    }
+                }
+                // -- idle lanes take rays pool_i .. from the pool --
+                if (!(st & ST_ACTIVE)) {
+                    const uint64_t idle = ~act;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    if (rank < pool_n) {
+                        const uint32_t e = pool_i + rank;
+                        pos0 = __uint_as_float(pool[0 * 64 + e]);
+                        pos1 = __uint_as_float(pool[1 * 64 + e]);
+                        pos2 = __uint_as_float(pool[2 * 64 + e]);
+                        dir0 = __uint_as_float(pool[3 * 64 + e]);
+                        dir1 = __uint_as_float(pool[4 * 64 + e]);
+                        dir2 = __uint_as_float(pool[5 * 64 + e]);
+                        dist = __uint_as_float(pool[6 * 64 + e]);
+                        out = pool[7 * 64 + e];
+                        y0 = 1.0f / dir0; y1 = 1.0f / dir1; y2 = 1.0f / dir2;
+                        tcur = 0.0f;
+                        ix = path_code(pos0, GE);
+                        iy = path_code(pos1, GE);
+                        iz = path_code(pos2, GE);
+                        st = ST_ACTIVE | ST_DESC | ST_ENTRY;  // steps = 0, L = 0
+                        lvl = 1;
+                        nidx = 0;
+                        if (use_table) {
+                            uint32_t cell = ((uint32_t)(ix >> (D - K)) << (2 * K)) | ((uint32_t)(iy >> (D - K)) << K) |
+                                            (uint32_t)(iz >> (D - K));
+                            uint32_t t = tbl[cell];
+                            if (t & kTopLeaf) {
+                                leaf_p = t & 0x07FFFFFFu;
+                                leaf_w = (t & kTopSolid) ? kSolidLeaf : kEmptyLeaf;
+                                st = ST_ACTIVE | ST_ENTRY | (((t >> 27) & 7u) << ST_L_SHIFT);
+                            } else {
+                                lvl = K + 1;
+                                nidx = t;
                             }
                         }
                     }
                 }
-                uint32_t taken = min(n_idle, avail);
-                next += taken;
-                if (next >= strip_end) {
-                    if (work_counter) {
-                        uint32_t s = 0;
-                        if ((tid & 63u) == 0) s = atomicAdd(work_counter, 1u);
-                        strip = __builtin_amdgcn_readfirstlane(s);
-                    } else {
-                        strip += n_waves;
-                    }
-                    if (strip < n_strips) {
-                        next = strip * strip_items;
-                        strip_end = min(next + strip_items, n_items);
-                    } else {
-                        next = strip_end = 0xFFFFFFFFu;
-                    }
-                }
+                const uint32_t took = min(n_idle, pool_n);
+                pool_i += took;
+                pool_n -= took;
                 act = __ballot((st & ST_ACTIVE) != 0u);
                 if (act == 0ull) {
-                    if (next == 0xFFFFFFFFu) break;
+                    if (pool_n == 0u && next == 0xFFFFFFFFu) break;
                     continue;
                 }
             }
@@ -582,12 +628,12 @@ __global__ __launch_bounds__(BLOCK, 8) void trace_stack_kernel(TraceArgs a, uint
                 uint32_t nm = stop_here ? ((st >> ST_M_SHIFT) & 7u) : mbits;
                 uint32_t c0n = (dir0 > 0.0f) ? 2u : 1u, c1n = (dir1 > 0.0f) ? 2u : 1u, c2n = (dir2 > 0.0f) ? 2u : 1u;
                 uint32_t ncode = ((nm & 1u) ? c0n : 0u) | ((nm & 2u) ? (c1n << 2) : 0u) | ((nm & 4u) ? (c2n << 4) : 0u);
-                if (stop_here && (st & ST_ENTRY)) ncode = entry_ncode;
+                if (stop_here && (st & ST_ENTRY)) ncode = out >> 26;
                 uint32_t value = too_deep ? 0xFF000000u : (solid ? leaf_p : (!inb ? 0x20202000u : 0xFF000000u));
                 uint32_t depth = (too_deep || (!solid && inb)) ? 100u : L;
                 uint32_t hit = (stop_here || inb) ? 1u : 0u;
                 if (!stop_here && !inb) ncode = 0u;  // the miss record carries no normal
-                write_hit(a.hits, out, value, dist + (stop_here ? tcur : tnew), stop_here ? (st & 0xFFu) : (inb ? steps_new : (st & 0xFFu)),
+                write_hit(a.hits, out & 0x03FFFFFFu, value, dist + (stop_here ? tcur : tnew), stop_here ? (st & 0xFFu) : (inb ? steps_new : (st & 0xFFu)),
                           depth, hit, ncode);
                 st = 0u;
             } else {
@@ -678,7 +724,7 @@ hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint3
 }
 
 constexpr int kStackBlock = 256;
-constexpr int kStackLevels = 16;
+constexpr int kStackLevels = 14;
 
 int stack_max_depth() { return kTopLevels + 1 + kStackLevels; }
 
@@ -686,7 +732,8 @@ template <bool GE>
 static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
     const uint32_t strip_items = li.strip_items ? li.strip_items : 64u;
     auto kern = trace_stack_kernel<kStackBlock, kStackLevels, kTopLevels, GE>;
-    size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + kStackLevels * kStackBlock) * sizeof(uint32_t);
+    size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + kStackLevels * kStackBlock + (kStackBlock / 64) * kPoolWords * 64) *
+                       sizeof(uint32_t);
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
         int n = 0;
