@@ -38,7 +38,7 @@ struct svo_ctx {
     int variant = SVO_VARIANT_STACK;
     int grid_blocks = 0;
     uint32_t refill_min = 8;
-    uint32_t strip_items = 128;
+    uint32_t strip_items = 64;
     bool dynamic_strips = true;
     // launch timing: a ring of (start, stop) event pairs recorded around trace launches
     std::vector<hipEvent_t> ev;  // 2 per slot
@@ -116,12 +116,12 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         ctx->defer_buf = nullptr;
         ctx->defer_items = 0;
         size_t want = wd.n_items < (1u << 16) ? (1u << 16) : wd.n_items;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->defer_buf, (want + 2) * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->defer_buf, (want + svo::kCounterWords + 1) * sizeof(uint32_t)));
         ctx->defer_items = want;
     }
     li.counters = ctx->defer_buf;
     li.work_counter = ctx->dynamic_strips ? ctx->defer_buf : nullptr;
-    li.defer = ctx->defer_buf ? ctx->defer_buf + 1 : nullptr;
+    li.defer = ctx->defer_buf ? ctx->defer_buf + svo::kCounterWords : nullptr;
     const size_t slot = ctx->ev_slots ? (ctx->ev_count % ctx->ev_slots) : 0;
     if (ctx->ev_slots) HIP_TRY(ctx, hipEventRecord(ctx->ev[2 * slot], ctx->stream));
     HIP_TRY(ctx, svo::launch_trace(a, li, ctx->stream));
@@ -249,7 +249,7 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
             ctx->refill_min = (uint32_t)value;
             return SVO_OK;
         case SVO_OPT_STRIP_ITEMS:
-            if (value < 64 || value > (1 << 20) || (value & 63)) return fail(ctx, SVO_ERR_ARG, "strip_items must be a multiple of 64");
+            if (value < 64 || value > 2048 || (value & 63)) return fail(ctx, SVO_ERR_ARG, "strip_items must be a multiple of 64 in [64, 2048]");
             ctx->strip_items = (uint32_t)value;
             return SVO_OK;
         case SVO_OPT_DYNAMIC_STRIPS:

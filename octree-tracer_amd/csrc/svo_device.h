@@ -13,6 +13,7 @@ constexpr uint32_t kMaxDescent = 31;           // descent guard (see oracle/svo_
 constexpr int kTopLevels = 3;                  // K: octree levels folded into the LDS top table
 constexpr int kTopEntries = 1 << (3 * kTopLevels);
 constexpr int kPathBits = 24;                  // D: integer path-code bits per axis
+constexpr int kCounterWords = 256;             // 8 claim counters, one per 128-byte line
 
 // Top-table entry (one per level-K cell, index = cx << 2K | cy << K | cz):
 //   bit 31 = 0: bits 0..26 = index of the child group at level K+1 (descent continues there)
@@ -54,9 +55,9 @@ struct LaunchInfo {
     int grid_blocks;         // 0 = auto
     int num_cus;
     uint32_t strip_items;    // STACK: pixel slots a wave claims at a time (multiple of 64)
-    uint32_t *counters;      // STACK: two device words zeroed per launch: {strip counter, deferred-ray count}
+    uint32_t *counters;      // STACK: kCounterWords + 1 device words zeroed per launch: claim counters, deferred count
     uint32_t *work_counter;  // STACK: counters + 0 for dynamic strip claiming, or nullptr (static round-robin)
-    uint32_t *defer;         // STACK: counters + 1 followed by one slot per item: rays handed to the RESTART kernel
+    uint32_t *defer;         // STACK: counters + kCounterWords: count, then one slot per item handed to RESTART
 };
 
 hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint32_t *top_table,

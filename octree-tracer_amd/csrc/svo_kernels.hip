@@ -409,23 +409,41 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
     const uint32_t n_items = a.work.n_items;
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + tid) >> 6);
-    const uint32_t n_strips = (n_items + strip_items - 1) / strip_items;
 
-    // wave-uniform work cursor
-    uint32_t strip, next, strip_end;
-    if (work_counter) {
-        uint32_t s = 0;
-        if (lane == 0) s = atomicAdd(work_counter, 1u);
-        strip = __builtin_amdgcn_readfirstlane(s);
-    } else {
-        strip = wave_id;
-    }
-    if (strip < n_strips) {
-        next = strip * strip_items;
-        strip_end = min(next + strip_items, n_items);
-    } else {
-        next = strip_end = 0xFFFFFFFFu;
-    }
+    // wave-uniform work cursor: a wave claims strips [next, strip_end) of strip_items items.
+    // Dynamic mode (work_counter): the strips are cut into kShards contiguous screen regions, each with its
+    // own claim counter on its own cache line.  A workgroup starts in region blockIdx % 8 -- workgroups are
+    // dealt round-robin over the 8 XCDs, so the waves sharing an L2 work on one screen region and walk it in
+    // order -- and moves on to the next region when its own is exhausted (work stealing keeps the tail short;
+    // a single counter would serialise at ~88 claims/us).  Static mode: strips dealt round-robin to waves.
+    constexpr uint32_t kShards = 8, kShardStride = 32;  // counters 128 B apart
+    const uint32_t n_strips = (n_items + strip_items - 1) / strip_items;
+    const uint32_t per_shard = (n_strips + kShards - 1) / kShards;
+    uint32_t strip = wave_id, shard_try = 0, next, strip_end;
+    auto claim = [&]() {
+        uint32_t s = 0xFFFFFFFFu;
+        if (work_counter) {
+            while (shard_try < kShards) {
+                const uint32_t sh = (blockIdx.x + shard_try) % kShards;
+                uint32_t k = 0;
+                if (lane == 0) k = atomicAdd(work_counter + sh * kShardStride, 1u);
+                k = __builtin_amdgcn_readfirstlane(k);
+                const uint32_t cand = sh * per_shard + k;
+                if (k < per_shard && cand < n_strips) { s = cand; break; }
+                shard_try += 1;
+            }
+        } else {
+            if (strip < n_strips) s = strip;
+            strip += n_waves;
+        }
+        if (s != 0xFFFFFFFFu) {
+            next = s * strip_items;
+            strip_end = min(next + strip_items, n_items);
+        } else {
+            next = strip_end = 0xFFFFFFFFu;
+        }
+    };
+    claim();
     uint32_t pool_n = 0, pool_i = 0;  // wave-uniform: rays waiting in the pool, index of the first
 
     // per-lane ray state
@@ -499,21 +517,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                     pool_n = (uint32_t)__popcll(am);
                     pool_i = 0u;
                     next += min(64u, strip_end - next);
-                    if (next >= strip_end) {
-                        if (work_counter) {
-                            uint32_t s = 0;
-                            if (lane == 0) s = atomicAdd(work_counter, 1u);
-                            strip = __builtin_amdgcn_readfirstlane(s);
-                        } else {
-                            strip += n_waves;
-                        }
-                        if (strip < n_strips) {
-                            next = strip * strip_items;
-                            strip_end = min(next + strip_items, n_items);
-                        } else {
-                            next = strip_end = 0xFFFFFFFFu;
-                        }
-                    }
+                    if (next >= strip_end) claim();
                 }
                 // -- idle lanes take rays pool_i .. from the pool --
                 if (!(st & ST_ACTIVE)) {
@@ -761,8 +765,8 @@ hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t
         hipLaunchKernelGGL(trace_restart_kernel, dim3(blocks), dim3(256), 0, stream, args, (const uint32_t *)nullptr);
         return hipGetLastError();
     }
-    // li.counters = {strip counter, deferred-ray count}: zeroed together ahead of the launch
-    hipError_t e = hipMemsetAsync(li.counters, 0, 2 * sizeof(uint32_t), stream);
+    // li.counters = {8 region claim counters (128 B apart), deferred-ray count}: zeroed together ahead of the launch
+    hipError_t e = hipMemsetAsync(li.counters, 0, (kCounterWords + 1) * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     e = (args.u.flags & SVO_F_MISC_BOOL) ? launch_stack<true>(args, li, stream) : launch_stack<false>(args, li, stream);
     if (e != hipSuccess) return e;

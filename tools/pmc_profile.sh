@@ -25,7 +25,7 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(out + "/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "trace_stack_kernel" in r["Kernel_Name"] or "trace_restart_kernel" in r["Kernel_Name"]:
+        if "trace_stack_kernel" in r["Kernel_Name"]:
             a = agg[r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
 res = {k: {"mean_per_launch": v[0] / v[1], "launches": v[1]} for k, v in sorted(agg.items())}
