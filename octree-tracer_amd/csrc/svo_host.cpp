@@ -367,7 +367,7 @@ size_t svo_rsvo_write(const svo_cpu_octree *t, uint8_t *out, size_t cap) {
             uint8_t m = 0;
             for (int i = 0; i < 8; i++) {
                 const auto &n = t->nodes[g + i];
-                if (n.pointer != kChunkOffset) m |= uint8_t(1u << i);
+                if (n.pointer != kChunkOffset || !n.value.is_zero()) m |= uint8_t(1u << i);  // interior, block or coloured leaf
                 if (n.pointer < kChunkOffset) nextf.push_back(n.pointer);
             }
             masks.push_back(m);
@@ -375,7 +375,7 @@ size_t svo_rsvo_write(const svo_cpu_octree *t, uint8_t *out, size_t cap) {
         // a non-empty child that is not interior is only representable on the last level
         size_t non_empty = 0;
         for (size_t g : frontier)
-            for (int i = 0; i < 8; i++) non_empty += t->nodes[g + i].pointer != kChunkOffset;
+            for (int i = 0; i < 8; i++) non_empty += t->nodes[g + i].pointer != kChunkOffset || !t->nodes[g + i].value.is_zero();
         if (!nextf.empty() && nextf.size() != non_empty) return 0;
         frontier.swap(nextf);
     }

@@ -1,0 +1,117 @@
+"""Oracle pinning: the reference has no tests or golden vectors, so the oracle is
+pinned by the hand-derivable known answers of SURVEY.md 8c and by the committed fixtures."""
+import numpy as np
+
+from conftest import GOLDEN, load_vox_fixture
+
+
+def test_word_encodings(O):
+    """KAT 1: octree.rs:28-30,164-166."""
+    t = O.Tree.new(0)
+    assert t.to_octree().tolist() == [0x80000000] * 8          # empty = VOXEL_OFFSET << 4
+    t.put_in_voxel((0.5, 0.5, 0.5), (255, 0, 0), 1)
+    assert t.to_octree()[7] == 0x8FF00000                      # Voxel(255,0,0).to_value()
+    t2 = O.Tree.new(0)
+    t2.put_in_voxel((-0.9, -0.9, -0.9), (1, 2, 3), 2)          # forces one subdivision: create_node(8) = 0x80
+    w = t2.to_octree()
+    assert w[0] == 0x00000080 and w.size == 16 and w[8] == ((O.VOXEL_OFFSET + 0x010203) << 4)
+
+
+def test_child_mask_bit_test(O):
+    """cpu_octree.rs:32-45: bit i of the mask -> child i is a block reference CHUNK_OFFSET + i % 8 + 1."""
+    t = O.Tree.new(0b01011011)
+    ptrs, rgb = t.raw()
+    for i in range(8):
+        if (0b01011011 >> i) & 1:
+            assert ptrs[i] == O.CHUNK_OFFSET + i + 1 and rgb[i].tolist() == [255, 0, 0]
+        else:
+            assert ptrs[i] == O.CHUNK_OFFSET and rgb[i].tolist() == [0, 0, 0]
+
+
+def test_node_counts_from_assets(O):
+    """KAT 3: 8 * (1 + #interior): small.vox 256 words, monu9.vox 65 184."""
+    for name, n_vox, n_words in (("small", 45, 256), ("monu9", 32832, 65184)):
+        size, xyzi, pal, n, crc = load_vox_fixture(name)
+        assert xyzi.shape[0] == n_vox and n == n_words
+        words = O.Tree.from_voxels(size, xyzi, pal).to_octree()
+        assert words.size == n_words
+        assert int(np.bitwise_xor.reduce(words * np.arange(1, words.size + 1, dtype=np.uint32))) == crc
+        solid = ((words >> 4) > O.VOXEL_OFFSET).sum()
+        assert solid == n_vox  # every voxel of the model is one solid leaf
+
+
+def test_single_level_rays(O):
+    """KATs 4-6: tree with only child 7 solid."""
+    words = np.array([0x80000000] * 7 + [0x8FF00000], dtype=np.uint32)
+    rays = np.array([[0.5, 0.5, -3, 0, 0, 1], [0.5, 0.5, -3, 0, 0, -1], [-0.5, -0.5, -3, 0, 0, 1]], dtype=np.float32)
+    h = O.trace_rays(words, rays)
+    i = O.unpack_info(h["info"])
+    # KAT 4: dist = 2, first leaf child 6 (empty), one step t = 1, normal (0,0,-1), hit index 7, t_hit = 3
+    assert h["value"][0] == 7 and h["t"][0] == 3.0 and i["steps"][0] == 1 and i["depth"][0] == 1 and i["hit"][0] == 1
+    assert h["normal_bits"][0] == (2 << 4)
+    # KAT 5: pointing away: ray_box_dist = 0 -> miss with value 0
+    assert h["value"][1] == 0 and i["hit"][1] == 0 and h["t"][1] == 0.0
+    # KAT 6: crosses the cube without hitting: value 0x20202000
+    assert h["value"][2] == 0x20202000 and i["hit"][2] == 0 and i["steps"][2] == 1
+
+
+def test_step_limit_sentinel(O):
+    """KAT 7: > 100 steps -> hit = true, value 0xFF000000, depth 100 (shader.wgsl:242-244)."""
+    z = np.load(f"{GOLDEN}/config1_small_256.npz")
+    hits = z["hits"].view(O.HIT_DTYPE).reshape(-1)
+    i = O.unpack_info(hits["info"])
+    capped = hits["value"] == 0xFF000000
+    assert capped.any()
+    assert (i["steps"][capped] == 101).all() and (i["depth"][capped] == 100).all() and (i["hit"][capped] == 1).all()
+
+
+def test_find_voxel_tie_breaks(O):
+    """shader.wgsl:138-150: `>` (default) vs `>=` (misc_bool) on a boundary position."""
+    words = np.array([(O.VOXEL_OFFSET + i + 1) << 4 for i in range(8)], dtype=np.uint32)
+    v, pos, d = O.find_voxel(words, (0.0, 0.0, 0.0), misc_bool=False)
+    assert (v, d, pos) == (0, 1, (-0.5, -0.5, -0.5))
+    v, pos, d = O.find_voxel(words, (0.0, 0.0, 0.0), misc_bool=True)
+    assert (v, d, pos) == (7, 1, (0.5, 0.5, 0.5))
+
+
+def test_scan_rules(O):
+    """KAT 8: compute.wgsl:34-46."""
+    VO = O.VOXEL_OFFSET
+    words = np.array([
+        ((VO + 5) << 4) | 4,    # leaf, counter 4 -> subdivide
+        ((VO + 5) << 4) | 3,    # leaf, counter 3 -> nothing
+        (VO << 4) | 15,         # empty leaf (not > VOXEL_OFFSET) -> nothing
+        (16 << 4) | 0,          # interior, counter 0 -> unsubdivide
+        (16 << 4) | 1,          # interior, counter 1 -> nothing
+        0,                      # zero word -> skipped
+        ((VO + 1) << 4) | 15,   # leaf, counter 15 -> subdivide
+        (24 << 4) | 0,          # interior, counter 0, but beyond node_length below
+    ], dtype=np.uint32)
+    sub, unsub = O.scan(words)
+    assert sub[0] == 2 and sub[1:3].tolist() == [0, 6]
+    assert unsub[0] == 2 and unsub[1:3].tolist() == [3, 7]
+    sub, unsub = O.scan(words, node_length=7)
+    assert unsub[0] == 1 and unsub[1] == 3
+
+
+def test_golden_regression(O, small_words):
+    """The committed config-1 records are what the oracle produces today (guards the oracle itself)."""
+    z = np.load(f"{GOLDEN}/config1_small_256.npz")
+    u = O.make_uniforms(width=256, height=256, flags=O.F_PAUSE_ADAPTIVE)
+    assert np.array_equal(np.array(u.camera_inverse, dtype=np.float32), z["camera_inverse"])
+    hits, stats = O.trace_frame(small_words, u, stats=True, threads=4)
+    assert np.array_equal(hits.reshape(-1).view(np.uint32).reshape(-1, 4), z["hits"])
+    assert np.array_equal(stats.reshape(-1, 2), z["stats"])
+    # perfect-reuse words never exceed the restart-from-root words
+    assert (stats[..., 1] <= stats[..., 0]).all()
+
+
+def test_counter_side_effect_is_order_independent(O, small_words):
+    """shader.wgsl:157-161 as a saturating count of visits: tiles in any order give the same words."""
+    u = O.make_uniforms(width=64, height=64, flags=0)  # adaptive on, no shadows
+    whole = O.count_frame(small_words, u)
+    a = O.count_frame(O.count_frame(small_words, u, tile=(0, 0, 64, 32)), u, tile=(0, 32, 64, 32))
+    b = O.count_frame(O.count_frame(small_words, u, tile=(0, 32, 64, 32)), u, tile=(0, 0, 64, 32))
+    assert np.array_equal(whole, a) and np.array_equal(whole, b)
+    assert np.array_equal(whole >> 4, small_words >> 4)  # pointers untouched
+    assert (whole & 15).max() == 15

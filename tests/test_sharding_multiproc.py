@@ -1,0 +1,73 @@
+"""The N > 1 path on CPU: two processes over gloo shard the frame's tiles round-robin, trace their own
+tiles (here with the oracle standing in for the GPU kernel), do the ONE gather of the design, and rank 0
+un-permutes.  Checks the sharding arithmetic and the collective the GPU ranks use with RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, W, H, tw, th, out_path):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    O = entry.load_oracle()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        words = pkg.scenes.random_tree(seed=5, max_depth=6, p_split=0.5, p_solid=0.35, max_words=1 << 17)
+        u = O.make_uniforms(width=W, height=H, flags=O.F_PAUSE_ADAPTIVE)
+        sh = pkg.sharding
+        n_pad = sh.padded_tile_count(W, H, tw, th, world)
+        n_mine = sh.local_tile_count(W, H, tw, th, rank, world)
+        local = torch.zeros((n_pad, th * tw, 4), dtype=torch.int32)
+        tiles_x = W // tw
+        for k in range(n_mine):  # the tiles svo_render_tiles(first_tile=rank, tile_stride=world) would trace
+            t = rank + k * world
+            ty, tx = divmod(t, tiles_x)
+            rec = O.trace_frame(words, u, tile=(tx * tw, ty * th, tw, th)).reshape(-1)
+            local[k] = torch.from_numpy(rec.view(np.uint32).reshape(-1, 4).view(np.int32).copy())
+        g = sh.gather_frame(local, rank, world)
+        if rank == 0:
+            frame = sh.assemble_frame(g, W, H, tw, th).contiguous().numpy().view(np.uint32)
+            want = O.trace_frame(words, u).reshape(-1).view(np.uint32).reshape(H, W, 4)
+            np.save(out_path, np.array([int(np.array_equal(frame, want))]))
+        else:
+            assert g is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H,tw,th", [(2, 96, 40, 32, 8), (3, 64, 48, 16, 8)])
+def test_tile_sharded_frame_over_gloo(tmp_path, world, W, H, tw, th):
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker, args=(world, _free_port(), W, H, tw, th, out), nprocs=world, join=True)
+    assert np.load(out)[0] == 1
+
+
+def test_sharding_arithmetic(pkg):
+    sh = pkg.sharding
+    assert [sh.local_tile_count(1920, 1080, 64, 8, r, 8) for r in range(8)] == [507, 507, 506, 506, 506, 506, 506, 506]
+    assert sh.padded_tile_count(1920, 1080, 64, 8, 8) == 507
+    assert sum(sh.local_tile_count(3840, 2160, 64, 8, r, 4) for r in range(4)) == 60 * 270
+    g = torch.arange(2 * 3 * 4 * 4, dtype=torch.int32).reshape(2, 3, 4, 4)  # world 2, 3 slots, 2x2 tiles
+    f = sh.assemble_frame(g, 4, 6, 2, 2)  # 2 x 3 tiles: tile t = slot * 2 + rank
+    assert f.shape == (6, 4, 4)
+    assert torch.equal(f[0:2, 2:4].reshape(4, 4), g[1, 0])  # tile 1 -> rank 1 slot 0
+    assert torch.equal(f[2:4, 0:2].reshape(4, 4), g[0, 1])  # tile 2 -> rank 0 slot 1
