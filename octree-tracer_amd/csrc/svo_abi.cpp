@@ -38,6 +38,14 @@ struct svo_ctx {
     int variant = SVO_VARIANT_STACK;
     int grid_blocks = 0;
     uint32_t refill_min = 8;
+    uint32_t prio_steps = 0;
+    // scheduling feedback (strip order from the previous frame of the same work layout)
+    bool schedule = true;
+    uint32_t *sched_cost = nullptr, *sched_order = nullptr;
+    size_t sched_cap = 0;
+    bool sched_valid = false;
+    svo::WorkDesc sched_key{};
+    uint32_t *debug_buf = nullptr;  // caller-provided device buffer for the per-wave timeline (diagnostics)
     uint32_t strip_items = 64;
     bool dynamic_strips = true;
     // launch timing: a ring of (start, stop) event pairs recorded around trace launches
@@ -105,6 +113,28 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     a.rgba = rgba;
     a.status = ctx->status;
     a.refill_min = ctx->refill_min;
+    a.prio_steps = ctx->prio_steps;
+    a.debug = ctx->debug_buf;
+    const bool stack = ctx->variant == SVO_VARIANT_STACK;
+    const uint32_t n_strips = (wd.n_items + 63u) / 64u;
+    if (stack && ctx->schedule) {
+        if (ctx->sched_cap < n_strips) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->sched_cost) (void)hipFree(ctx->sched_cost);
+            if (ctx->sched_order) (void)hipFree(ctx->sched_order);
+            ctx->sched_cost = ctx->sched_order = nullptr;
+            ctx->sched_cap = 0;
+            ctx->sched_valid = false;
+            size_t want = n_strips < 4096 ? 4096 : n_strips;
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->sched_cost, want * sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->sched_order, (want + 8 * 24 + 8) * sizeof(uint32_t)));
+            ctx->sched_cap = want;
+        }
+        // the order is only meaningful for the same work layout (same pixels behind every strip)
+        if (ctx->sched_valid && memcmp(&ctx->sched_key, &wd, sizeof(wd)) != 0) ctx->sched_valid = false;
+        a.order = ctx->sched_valid ? ctx->sched_order : nullptr;
+        a.order_cap = (n_strips + 7u) / 8u + 16u;  // a list holds ceil(n_class / 8) strips of each of the 16 classes
+    }
     svo::LaunchInfo li{};
     li.variant = ctx->variant;
     li.grid_blocks = ctx->grid_blocks;
@@ -113,6 +143,8 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     if (ctx->variant == SVO_VARIANT_STACK && ctx->defer_items < wd.n_items) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->defer_buf) (void)hipFree(ctx->defer_buf);
+    if (ctx->sched_cost) (void)hipFree(ctx->sched_cost);
+    if (ctx->sched_order) (void)hipFree(ctx->sched_order);
         ctx->defer_buf = nullptr;
         ctx->defer_items = 0;
         size_t want = wd.n_items < (1u << 16) ? (1u << 16) : wd.n_items;
@@ -128,6 +160,13 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     if (ctx->ev_slots) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[2 * slot + 1], ctx->stream));
         ctx->ev_count++;
+    }
+    if (stack && ctx->schedule) {
+        // feedback for the next frame: per-strip cost of this frame, sorted most expensive first
+        HIP_TRY(ctx, svo::launch_strip_feedback(wd, hits, ctx->sched_cost, ctx->sched_order, n_strips,
+                                                (n_strips + 7u) / 8u + 16u, ctx->stream));
+        ctx->sched_key = wd;
+        ctx->sched_valid = true;
     }
     return SVO_OK;
 }
@@ -201,6 +240,8 @@ int svo_ctx_destroy(svo_ctx *ctx) {
     if (ctx->top_table) (void)hipFree(ctx->top_table);
     if (ctx->status) (void)hipFree(ctx->status);
     if (ctx->defer_buf) (void)hipFree(ctx->defer_buf);
+    if (ctx->sched_cost) (void)hipFree(ctx->sched_cost);
+    if (ctx->sched_order) (void)hipFree(ctx->sched_order);
     if (ctx->scan_sub) (void)hipFree(ctx->scan_sub);
     if (ctx->scan_unsub) (void)hipFree(ctx->scan_unsub);
     if (ctx->stage) (void)hipFree(ctx->stage);
@@ -254,6 +295,17 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
             return SVO_OK;
         case SVO_OPT_DYNAMIC_STRIPS:
             ctx->dynamic_strips = value != 0;
+            return SVO_OK;
+        case SVO_OPT_SCHEDULE:
+            ctx->schedule = value != 0;
+            ctx->sched_valid = false;
+            return SVO_OK;
+        case SVO_OPT_DEBUG_BUFFER:
+            ctx->debug_buf = (uint32_t *)(uintptr_t)value;  // device pointer, >= 16 B per wave of the grid; 0 = off
+            return SVO_OK;
+        case SVO_OPT_PRIO_STEPS:
+            if (value < 0 || value > 255) return fail(ctx, SVO_ERR_ARG, "prio_steps must be 0..255");
+            ctx->prio_steps = (uint32_t)value;
             return SVO_OK;
         default:
             return fail(ctx, SVO_ERR_ARG, "unknown option");

@@ -48,6 +48,10 @@ struct TraceArgs {
     uint32_t *rgba;             // may be nullptr
     uint32_t *status;           // device word: bit 0 set when a STACK-variant descent exceeded kPathBits
     uint32_t refill_min;
+    const uint32_t *order;      // STACK, optional: schedule built by strip_order_kernel (8 lengths + 8 lists)
+    uint32_t order_cap;         // entries reserved per list
+    uint32_t *debug;            // optional: 4 words per wave (start, queue-dry, end ticks of 10 ns, rounds)
+    uint32_t prio_steps;        // STACK: waves carrying rays with at least this many steps raise their priority (0 = off)
 };
 
 struct LaunchInfo {
@@ -63,7 +67,10 @@ struct LaunchInfo {
 hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint32_t *top_table,
                                   hipStream_t stream);
 hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream);
-int stack_max_depth();  // deepest tree level the STACK variant resolves
+int stack_max_depth();
+// cost[s] = max step count of strip s in `hits`; order = strips sorted by descending cost
+hipError_t launch_strip_feedback(const WorkDesc &work, const svo_hit *hits, uint32_t *cost, uint32_t *order,
+                                 uint32_t n_strips, uint32_t cap, hipStream_t stream);  // deepest tree level the STACK variant resolves
 hipError_t launch_scan(const uint32_t *nodes, uint32_t n_words, uint32_t node_length, uint32_t *sub,
                        uint32_t *unsub, uint32_t capacity, hipStream_t stream);
 

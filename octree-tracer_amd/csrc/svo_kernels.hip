@@ -378,18 +378,25 @@ constexpr uint32_t ST_L_MASK = 31u << ST_L_SHIFT, ST_M_MASK = 7u << ST_M_SHIFT;
 
 // Ray pool: a wave generates the rays of up to 64 work items at once, with every lane busy (lanes that
 // are still traversing compute a ray for somebody else), compacts the ones that enter the cube into LDS,
-// and idle lanes later pick them up.  Ray generation (2 mat-vecs, 11 divisions, a square root) is thereby
-// paid once per 64 rays at full lane utilisation instead of on every refill.
-constexpr int kPoolWords = 8;  // pos.xyz, dir.xyz (biased), dist, out | entry normal code << 26
+// and idle lanes later pick them up.  Ray generation and set-up (2 mat-vecs, 14 IEEE divisions, a square
+// root, the entry path codes) are thereby paid once per 64 rays at full lane utilisation instead of on
+// every refill.  Pool record: P.xyz, Dr.xyz, Y.xyz (position, biased direction and its reciprocal, all in
+// grid units, see below), dist, out | entry normal code << 26, path codes x, y, z.
+constexpr int kPoolWords = 14;
 
+// The traversal runs in GRID UNITS: positions and directions are pre-multiplied by 2^23 (the path-code
+// scale).  Scaling by a power of two commutes with every IEEE rounding involved (no overflow/underflow on
+// a clean ray), so  A = (C - P) + H,  t = A / Dr,  G = (P + Dr * t) +- K  are exactly 2^23 times the
+// reference's  a,  the same t,  and  2^23 * voxel_pos  -- and G is what the path codes need.
 template <int BLOCK, int NS, int K, bool GE>
-__global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
+__global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
     constexpr int SMAX = K + 1 + NS;   // last level kept on the LDS stack = deepest level resolved
-    static_assert(SMAX <= D, "stack deeper than the path codes");
+    static_assert(SMAX <= D - 1, "stack deeper than the path codes");
     constexpr int TBL = 1 << (3 * K);
+    constexpr float kScale = 8388608.0f;  // 2^23
     extern __shared__ uint32_t lds[];
     uint32_t *tbl = lds;                          // TBL entries
     uint32_t *stk = lds + TBL;                    // [NS][BLOCK]
@@ -399,11 +406,8 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
     const uint32_t lane = tid & 63u;
     uint32_t *pool = pool_all + (tid >> 6) * (kPoolWords * 64);
     const rsrc_t rs = make_rsrc(a.nodes, a.n_words);
-    const bool counter_hits = (a.u.flags & SVO_F_PAUSE_ADAPTIVE) && (a.u.flags & SVO_F_SHOW_HITS);
-    const bool use_table = (a.top_table != nullptr) && !counter_hits;
 
-    if (use_table)
-        for (uint32_t i = tid; i < (uint32_t)TBL; i += BLOCK) tbl[i] = a.top_table[i];
+    for (uint32_t i = tid; i < (uint32_t)TBL; i += BLOCK) tbl[i] = a.top_table[i];
     __syncthreads();
 
     const uint32_t n_items = a.work.n_items;
@@ -419,6 +423,10 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
     constexpr uint32_t kShards = 8, kShardStride = 32;  // counters 128 B apart
     const uint32_t n_strips = (n_items + strip_items - 1) / strip_items;
     const uint32_t per_shard = (n_strips + kShards - 1) / kShards;
+    // a.order (optional): strip numbers sorted by the cost they had in the previous frame, longest rays first
+    // (LPT scheduling: a ray is a serial chain of up to 101 rounds, so the long ones must start early or the
+    // whole chip waits for them at the end); layout and rationale at strip_order_kernel.
+    const uint32_t *order = a.order;  // 8 list lengths, then 8 lists of a.order_cap strip numbers
     uint32_t strip = wave_id, shard_try = 0, next, strip_end;
     auto claim = [&]() {
         uint32_t s = 0xFFFFFFFFu;
@@ -428,8 +436,12 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                 uint32_t k = 0;
                 if (lane == 0) k = atomicAdd(work_counter + sh * kShardStride, 1u);
                 k = __builtin_amdgcn_readfirstlane(k);
-                const uint32_t cand = sh * per_shard + k;
-                if (k < per_shard && cand < n_strips) { s = cand; break; }
+                if (order) {
+                    if (k < order[sh]) { s = order[kShards + sh * a.order_cap + k]; break; }
+                } else {
+                    const uint32_t cand = sh * per_shard + k;
+                    if (k < per_shard && cand < n_strips) { s = cand; break; }
+                }
                 shard_try += 1;
             }
         } else {
@@ -437,6 +449,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
             strip += n_waves;
         }
         if (s != 0xFFFFFFFFu) {
+            s = __builtin_amdgcn_readfirstlane(s);
             next = s * strip_items;
             strip_end = min(next + strip_items, n_items);
         } else {
@@ -445,11 +458,15 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
     };
     claim();
     uint32_t pool_n = 0, pool_i = 0;  // wave-uniform: rays waiting in the pool, index of the first
+    // optional per-wave timeline (diagnostic builds of the host set a.debug): start, queue-dry, end in 10 ns ticks
+    uint64_t t_begin = 0, t_dry = 0;
+    uint32_t n_rounds = 0;
+    if (a.debug) t_begin = __builtin_amdgcn_s_memrealtime();
 
     // per-lane ray state
     uint32_t st = 0;                  // packed, see ST_*
     uint32_t out = 0;                 // bits 0..25 output index, 26..31 entry normal code
-    float pos0 = 0, pos1 = 0, pos2 = 0, dir0 = 1, dir1 = 1, dir2 = 1, y0 = 1, y1 = 1, y2 = 1;
+    float P0 = 0, P1 = 0, P2 = 0, Dr0 = 1, Dr1 = 1, Dr2 = 1, Y0 = 1, Y1 = 1, Y2 = 1;
     float dist = 0.0f, tcur = 0.0f;
     int32_t ix = 0, iy = 0, iz = 0;
     uint32_t lvl = 1, nidx = 0;       // next level to read and the child group it lives in
@@ -457,6 +474,21 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
 
     // leaf words standing in for table hits (only solidity is read from them)
     constexpr uint32_t kEmptyLeaf = kVoxelOffset << 4, kSolidLeaf = (kVoxelOffset + 1u) << 4;
+
+    // start (or restart) a descent from the top table; leaves met above level K+1 need no descent at all
+    auto from_table = [&]() {
+        const uint32_t cell = ((uint32_t)(ix >> (D - K)) << (2 * K)) | ((uint32_t)(iy >> (D - K)) << K) |
+                              (uint32_t)(iz >> (D - K));
+        const uint32_t t = tbl[cell];
+        if (t & kTopLeaf) {
+            leaf_p = t & 0x07FFFFFFu;
+            leaf_w = (t & kTopSolid) ? kSolidLeaf : kEmptyLeaf;
+            st = (st & ~(ST_L_MASK | ST_DESC)) | (((t >> 27) & 7u) << ST_L_SHIFT);
+        } else {
+            lvl = K + 1;
+            nidx = t;
+        }
+    };
 
     for (;;) {
         // ---- 1. refill idle lanes from the ray pool (ballot compaction) ----
@@ -469,7 +501,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                     // -- generate the next (up to) 64 rays, all lanes --
                     const uint32_t q = next + lane;
                     bool alive = false;
-                    float gp0 = 0, gp1 = 0, gp2 = 0, gd0 = 0, gd1 = 0, gd2 = 0, gdist = 0;
+                    float gp0 = 0, gp1 = 0, gp2 = 0, gd0 = 1, gd1 = 1, gd2 = 1, gdist = 0;
                     uint32_t gout = 0;
                     if (q < strip_end) {
                         ItemFast it = decode_item_fast(a.work, q);
@@ -505,19 +537,27 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                     if (alive) {
                         const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32),
                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-                        pool[0 * 64 + slot] = __float_as_uint(gp0);
-                        pool[1 * 64 + slot] = __float_as_uint(gp1);
-                        pool[2 * 64 + slot] = __float_as_uint(gp2);
+                        gd0 *= kScale; gd1 *= kScale; gd2 *= kScale;  // exact: power-of-two scaling
+                        pool[0 * 64 + slot] = __float_as_uint(gp0 * kScale);
+                        pool[1 * 64 + slot] = __float_as_uint(gp1 * kScale);
+                        pool[2 * 64 + slot] = __float_as_uint(gp2 * kScale);
                         pool[3 * 64 + slot] = __float_as_uint(gd0);
                         pool[4 * 64 + slot] = __float_as_uint(gd1);
                         pool[5 * 64 + slot] = __float_as_uint(gd2);
-                        pool[6 * 64 + slot] = __float_as_uint(gdist);
-                        pool[7 * 64 + slot] = gout;
+                        pool[6 * 64 + slot] = __float_as_uint(1.0f / gd0);  // RN(1 / Dr) = 2^-23 * RN(1 / dir)
+                        pool[7 * 64 + slot] = __float_as_uint(1.0f / gd1);
+                        pool[8 * 64 + slot] = __float_as_uint(1.0f / gd2);
+                        pool[9 * 64 + slot] = __float_as_uint(gdist);
+                        pool[10 * 64 + slot] = gout;
+                        pool[11 * 64 + slot] = (uint32_t)path_code(gp0, GE);
+                        pool[12 * 64 + slot] = (uint32_t)path_code(gp1, GE);
+                        pool[13 * 64 + slot] = (uint32_t)path_code(gp2, GE);
                     }
                     pool_n = (uint32_t)__popcll(am);
                     pool_i = 0u;
                     next += min(64u, strip_end - next);
                     if (next >= strip_end) claim();
+                    if (a.debug && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
                 }
                 // -- idle lanes take rays pool_i .. from the pool --
                 if (!(st & ST_ACTIVE)) {
@@ -526,35 +566,23 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                     if (rank < pool_n) {
                         const uint32_t e = pool_i + rank;
-                        pos0 = __uint_as_float(pool[0 * 64 + e]);
-                        pos1 = __uint_as_float(pool[1 * 64 + e]);
-                        pos2 = __uint_as_float(pool[2 * 64 + e]);
-                        dir0 = __uint_as_float(pool[3 * 64 + e]);
-                        dir1 = __uint_as_float(pool[4 * 64 + e]);
-                        dir2 = __uint_as_float(pool[5 * 64 + e]);
-                        dist = __uint_as_float(pool[6 * 64 + e]);
-                        out = pool[7 * 64 + e];
-                        y0 = 1.0f / dir0; y1 = 1.0f / dir1; y2 = 1.0f / dir2;
+                        P0 = __uint_as_float(pool[0 * 64 + e]);
+                        P1 = __uint_as_float(pool[1 * 64 + e]);
+                        P2 = __uint_as_float(pool[2 * 64 + e]);
+                        Dr0 = __uint_as_float(pool[3 * 64 + e]);
+                        Dr1 = __uint_as_float(pool[4 * 64 + e]);
+                        Dr2 = __uint_as_float(pool[5 * 64 + e]);
+                        Y0 = __uint_as_float(pool[6 * 64 + e]);
+                        Y1 = __uint_as_float(pool[7 * 64 + e]);
+                        Y2 = __uint_as_float(pool[8 * 64 + e]);
+                        dist = __uint_as_float(pool[9 * 64 + e]);
+                        out = pool[10 * 64 + e];
+                        ix = (int32_t)pool[11 * 64 + e];
+                        iy = (int32_t)pool[12 * 64 + e];
+                        iz = (int32_t)pool[13 * 64 + e];
                         tcur = 0.0f;
-                        ix = path_code(pos0, GE);
-                        iy = path_code(pos1, GE);
-                        iz = path_code(pos2, GE);
                         st = ST_ACTIVE | ST_DESC | ST_ENTRY;  // steps = 0, L = 0
-                        lvl = 1;
-                        nidx = 0;
-                        if (use_table) {
-                            uint32_t cell = ((uint32_t)(ix >> (D - K)) << (2 * K)) | ((uint32_t)(iy >> (D - K)) << K) |
-                                            (uint32_t)(iz >> (D - K));
-                            uint32_t t = tbl[cell];
-                            if (t & kTopLeaf) {
-                                leaf_p = t & 0x07FFFFFFu;
-                                leaf_w = (t & kTopSolid) ? kSolidLeaf : kEmptyLeaf;
-                                st = ST_ACTIVE | ST_ENTRY | (((t >> 27) & 7u) << ST_L_SHIFT);
-                            } else {
-                                lvl = K + 1;
-                                nidx = t;
-                            }
-                        }
+                        from_table();
                     }
                 }
                 const uint32_t took = min(n_idle, pool_n);
@@ -570,90 +598,101 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
             break;
         }
 
+        n_rounds += 1;
+        // Old rays decide when the kernel ends (a ray is a serial chain of up to 101 dependent rounds, and the
+        // last ones drain after the work queue is empty): waves that carry rays past a_prio_steps steps get
+        // issue priority over the waves they share a SIMD with.
+        if (a.prio_steps != 0u) {
+            const bool old_rays = __ballot((st & ST_ACTIVE) && ((st & 0xFFu) >= a.prio_steps)) != 0ull;
+            if (old_rays) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        }
+
         // ---- 2. descent: one dependent word per level below the restart level ----
         if (st & ST_DESC) {
-            uint32_t p, w;
-            uint32_t sp = (lvl > (uint32_t)SBASE - 1u ? lvl - ((uint32_t)SBASE - 1u) : 0u) * BLOCK + tid;  // slot of level lvl+1
+            uint32_t off, w;
+            uint32_t sh = (uint32_t)D - lvl;                 // bit of the path codes that selects the child
+            int32_t rem = (int32_t)SMAX - 1 - (int32_t)lvl;  // < 0 once level SMAX is reached
+            uint32_t sp = (lvl - (uint32_t)(SBASE - 1)) * BLOCK + tid;  // stack slot of level lvl + 1 (lvl >= K + 1)
             for (;;) {
-                uint32_t sh = (uint32_t)D - lvl;
-                uint32_t child = (__builtin_amdgcn_ubfe((uint32_t)ix, sh, 1u) << 2) |
-                                 (__builtin_amdgcn_ubfe((uint32_t)iy, sh, 1u) << 1) |
-                                 __builtin_amdgcn_ubfe((uint32_t)iz, sh, 1u);
-                p = nidx + child;
-                w = load_word(rs, p);
-                // leaf (pointer >= VOXEL_OFFSET <=> word >= VOXEL_OFFSET << 4), or deeper than SMAX (refused)
-                if (w >= (kVoxelOffset << 4) || lvl >= (uint32_t)SMAX) break;
-                lvl += 1;
+                const uint32_t child = (__builtin_amdgcn_ubfe((uint32_t)ix, sh, 1u) << 2) |
+                                       (__builtin_amdgcn_ubfe((uint32_t)iy, sh, 1u) << 1) |
+                                       __builtin_amdgcn_ubfe((uint32_t)iz, sh, 1u);
+                off = (nidx + child) << 2;
+                w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
+                // stop on a leaf (word >= VOXEL_OFFSET << 4 = sign bit) or at level SMAX (deeper trees are refused)
+                if ((int32_t)(w | (uint32_t)rem) < 0) break;
                 nidx = w >> 4;
-                stk[sp] = nidx;  // without the table levels below SBASE all land in slot 0, rewritten at SBASE
-                sp += (lvl >= (uint32_t)SBASE) ? BLOCK : 0u;
+                stk[sp] = nidx;
+                sp += BLOCK;
+                sh -= 1u;
+                rem -= 1;
             }
-            leaf_p = p;
+            lvl = (uint32_t)D - sh;
+            leaf_p = off >> 2;
             leaf_w = w;
             st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
         }
 
-        // ---- 3. hit test / DDA step (shader.wgsl:215-244), clean rays only ----
+        // ---- 3. hit test / DDA step (shader.wgsl:215-244), clean rays, grid units ----
         if (st & ST_ACTIVE) {
             const uint32_t L = (st >> ST_L_SHIFT) & 31u;
             const bool too_deep = leaf_w < (kVoxelOffset << 4);  // descent stopped on an interior word
-            const bool solid = counter_hits ? ((leaf_w & 15u) > 0u) : ((leaf_w >> 4) != kVoxelOffset);
-            // leaf centre from the path code: exact, equals the reference's accumulated node_pos
+            const bool solid = (leaf_w >> 4) != kVoxelOffset;
+            // leaf centre in grid units straight from the path code: keep the top L bits, set the next one
             const uint32_t sh = (uint32_t)D - L;
-            const float inv = __uint_as_float((127u - L) << 23);  // 2^-L = voxel_size / 2
-            const int32_t bias = 1 - (1 << L);
-            const float c0 = (float)(((ix >> sh) << 1) + bias) * inv;
-            const float c1 = (float)(((iy >> sh) << 1) + bias) * inv;
-            const float c2 = (float)(((iz >> sh) << 1) + bias) * inv;
+            const uint32_t keep = 0xFFFFFFFFu << sh, halfbit = 1u << (sh - 1u);
+            const float C0 = (float)((int32_t)(((uint32_t)ix & keep) | halfbit) - 8388608);
+            const float C1 = (float)((int32_t)(((uint32_t)iy & keep) | halfbit) - 8388608);
+            const float C2 = (float)((int32_t)(((uint32_t)iz & keep) | halfbit) - 8388608);
+            const float Hm = __uint_as_float((150u - L) << 23);  // 2^(23-L) = 2^23 * voxel_size / 2
             // r_sign * voxel_size / 2 = copysign(2^-L, dir): dir is never 0 or NaN on a clean ray
-            const float t0 = div_by_recip((c0 - pos0) + copysign_bits(inv, dir0), dir0, y0);
-            const float t1 = div_by_recip((c1 - pos1) + copysign_bits(inv, dir1), dir1, y1);
-            const float t2 = div_by_recip((c2 - pos2) + copysign_bits(inv, dir2), dir2, y2);
+            const float t0 = div_by_recip((C0 - P0) + copysign_bits(Hm, Dr0), Dr0, Y0);
+            const float t1 = div_by_recip((C1 - P1) + copysign_bits(Hm, Dr1), Dr1, Y1);
+            const float t2 = div_by_recip((C2 - P2) + copysign_bits(Hm, Dr2), Dr2, Y2);
             // no NaNs here, so IEEE minNum equals the oracle's (b < a) ? b : a up to the sign of a zero,
             // which no later value depends on
             const float t12 = __builtin_fminf(t1, t2), t20 = __builtin_fminf(t2, t0), t01 = __builtin_fminf(t0, t1);
             const bool m0 = t0 <= t12, m1 = t1 <= t20, m2 = t2 <= t01;
             const float tnew = __builtin_fminf(t01, t2);
             // voxel_pos = pos + dir * t - normal * 2e-6, normal = mask * -sign(dir): subtracting -k is adding k
-            float vp0 = pos0 + dir0 * tnew, vp1 = pos1 + dir1 * tnew, vp2 = pos2 + dir2 * tnew;
-            vp0 = m0 ? vp0 + copysign_bits(0.000002f, dir0) : vp0;
-            vp1 = m1 ? vp1 + copysign_bits(0.000002f, dir1) : vp1;
-            vp2 = m2 ? vp2 + copysign_bits(0.000002f, dir2) : vp2;
-            const bool inb = (__builtin_fmaxf(__builtin_fmaxf(vp0, vp1), vp2) < 1.0f) &&
-                             (__builtin_fminf(__builtin_fminf(vp0, vp1), vp2) >= -1.0f);
+            constexpr float kNudge = 0.000002f * 8388608.0f;  // exact product
+            float G0 = P0 + Dr0 * tnew, G1 = P1 + Dr1 * tnew, G2 = P2 + Dr2 * tnew;
+            G0 = m0 ? G0 + copysign_bits(kNudge, Dr0) : G0;
+            G1 = m1 ? G1 + copysign_bits(kNudge, Dr1) : G1;
+            G2 = m2 ? G2 + copysign_bits(kNudge, Dr2) : G2;
+            const bool inb = (__builtin_fmaxf(__builtin_fmaxf(G0, G1), G2) < kScale) &&
+                             (__builtin_fminf(__builtin_fminf(G0, G1), G2) >= -kScale);
             const bool stop_here = too_deep || solid;         // finish before stepping
             const uint32_t steps_new = (st & 0xFFu) + 1u;
             const bool capped = steps_new > 100u;
-            const bool fin = stop_here || !inb || capped;
-            if (fin) {
+            const uint32_t mbits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u);
+            if (stop_here || !inb || capped) {
                 if (too_deep) atomicOr(a.status, 1u);
-                const uint32_t mbits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u);
                 // normal of the record: the step just taken (capped), the previous one (solid / too deep) or none (left the cube)
                 uint32_t nm = stop_here ? ((st >> ST_M_SHIFT) & 7u) : mbits;
-                uint32_t c0n = (dir0 > 0.0f) ? 2u : 1u, c1n = (dir1 > 0.0f) ? 2u : 1u, c2n = (dir2 > 0.0f) ? 2u : 1u;
+                uint32_t c0n = (Dr0 > 0.0f) ? 2u : 1u, c1n = (Dr1 > 0.0f) ? 2u : 1u, c2n = (Dr2 > 0.0f) ? 2u : 1u;
                 uint32_t ncode = ((nm & 1u) ? c0n : 0u) | ((nm & 2u) ? (c1n << 2) : 0u) | ((nm & 4u) ? (c2n << 4) : 0u);
                 if (stop_here && (st & ST_ENTRY)) ncode = out >> 26;
                 uint32_t value = too_deep ? 0xFF000000u : (solid ? leaf_p : (!inb ? 0x20202000u : 0xFF000000u));
                 uint32_t depth = (too_deep || (!solid && inb)) ? 100u : L;
                 uint32_t hit = (stop_here || inb) ? 1u : 0u;
                 if (!stop_here && !inb) ncode = 0u;  // the miss record carries no normal
-                write_hit(a.hits, out & 0x03FFFFFFu, value, dist + (stop_here ? tcur : tnew), stop_here ? (st & 0xFFu) : (inb ? steps_new : (st & 0xFFu)),
-                          depth, hit, ncode);
+                write_hit(a.hits, out & 0x03FFFFFFu, value, dist + (stop_here ? tcur : tnew),
+                          (!stop_here && inb) ? steps_new : (st & 0xFFu), depth, hit, ncode);
                 st = 0u;
             } else {
                 tcur = tnew;
-                const uint32_t mbits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u);
                 st = ((st & ~(ST_M_MASK | ST_ENTRY | 0xFFu)) | (mbits << ST_M_SHIFT) | steps_new) | ST_DESC;
-                // new path codes: the position is inside [-1, 1), so no clamping of g
+                // new path codes: the position is inside the cube, so no clamping of G
                 int32_t jx, jy, jz;
                 if (GE) {
-                    jx = (int32_t)floorf(vp0 * 8388608.0f) + 8388608;
-                    jy = (int32_t)floorf(vp1 * 8388608.0f) + 8388608;
-                    jz = (int32_t)floorf(vp2 * 8388608.0f) + 8388608;
+                    jx = (int32_t)floorf(G0) + 8388608;
+                    jy = (int32_t)floorf(G1) + 8388608;
+                    jz = (int32_t)floorf(G2) + 8388608;
                 } else {
-                    jx = max((int32_t)ceilf(vp0 * 8388608.0f) + 8388607, 0);
-                    jy = max((int32_t)ceilf(vp1 * 8388608.0f) + 8388607, 0);
-                    jz = max((int32_t)ceilf(vp2 * 8388608.0f) + 8388607, 0);
+                    jx = max((int32_t)ceilf(G0) + 8388607, 0);
+                    jy = max((int32_t)ceilf(G1) + 8388607, 0);
+                    jz = max((int32_t)ceilf(G2) + 8388607, 0);
                 }
                 const uint32_t diff = (uint32_t)((ix ^ jx) | (iy ^ jy) | (iz ^ jz));
                 // levels shared by the old and new path: clz over the 24-bit codes (diff == 0: all 24)
@@ -661,27 +700,21 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                 ix = jx; iy = jy; iz = jz;
                 const uint32_t r = min(min(c + 1u, L), (uint32_t)SMAX);
                 if (r <= (uint32_t)(K + 1)) {
-                    lvl = 1;
-                    nidx = 0;
-                    if (use_table) {
-                        uint32_t cell = ((uint32_t)(ix >> (D - K)) << (2 * K)) | ((uint32_t)(iy >> (D - K)) << K) |
-                                        (uint32_t)(iz >> (D - K));
-                        uint32_t e = tbl[cell];
-                        if (e & kTopLeaf) {
-                            leaf_p = e & 0x07FFFFFFu;
-                            leaf_w = (e & kTopSolid) ? kSolidLeaf : kEmptyLeaf;
-                            st = (st & ~(ST_L_MASK | ST_DESC)) | (((e >> 27) & 7u) << ST_L_SHIFT);
-                        } else {
-                            lvl = K + 1;
-                            nidx = e;
-                        }
-                    }
+                    from_table();
                 } else {
                     lvl = r;
                     nidx = stk[(r - SBASE) * BLOCK + tid];
                 }
             }
         }
+    }
+    if (a.debug && lane == 0) {
+        uint64_t t_end = __builtin_amdgcn_s_memrealtime();
+        uint32_t *d = a.debug + 4u * wave_id;
+        d[0] = (uint32_t)t_begin;
+        d[1] = (uint32_t)(t_dry ? t_dry : t_end);
+        d[2] = (uint32_t)t_end;
+        d[3] = n_rounds;
     }
 }
 
@@ -718,9 +751,94 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t *nodes, uint32
 }
 
 // ---------------------------------------------------------------------------------------------
+// Scheduling feedback: cost of every 64-item strip in the frame just traced (the largest step count among
+// its rays) and the strip order for the next frame, most expensive first (counting sort on 0..101).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void strip_cost_kernel(WorkDesc work, const svo_hit *hits, uint32_t *cost,
+                                                         uint32_t n_strips) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = gridDim.x * 4u;
+    for (uint32_t s = wave; s < n_strips; s += n_waves) {
+        ItemFast it = decode_item_fast(work, s * 64u + lane);
+        uint32_t steps = 0;
+        if (it.valid) steps = reinterpret_cast<const uint4 *>(hits)[it.out].z & 0xFFu;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, o));
+        if (lane == 0) cost[s] = steps;
+    }
+}
+
+// Schedule for the next frame.  Strips fall into 16 cost classes (steps / 8).  Classes are walked from the
+// most expensive down; inside a class the strips stay in screen order and are cut into 8 contiguous
+// segments, one per claim counter (= per XCD, see the kernel).  So every XCD starts its long rays first,
+// gets an equal share of every class, and still walks screen-contiguous runs (node-cache locality).
+// Output: sched[0..7] = entries per list, then 8 lists of `cap` strip numbers each.
+__global__ __launch_bounds__(1024) void strip_order_kernel(const uint32_t *cost, uint32_t *sched, uint32_t n_strips,
+                                                           uint32_t cap) {
+    constexpr uint32_t kBins = 16, kThreads = 1024, kLists = 8;
+    __shared__ uint32_t counts[kBins][kThreads + 1];  // per class, per thread chunk (exclusive scan in place)
+    __shared__ uint32_t seglen[kBins];                 // strips of a class per list
+    __shared__ uint32_t list_base[kBins][kLists];      // where a class starts inside each list
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = (n_strips + kThreads - 1) / kThreads;
+    const uint32_t lo = min(tid * chunk, n_strips), hi = min(lo + chunk, n_strips);
+    uint32_t local[kBins];
+#pragma unroll
+    for (uint32_t b = 0; b < kBins; b++) local[b] = 0;
+    for (uint32_t s = lo; s < hi; s++) {
+        const uint32_t b = min(cost[s] >> 3, kBins - 1);
+#pragma unroll
+        for (uint32_t k = 0; k < kBins; k++) local[k] += (k == b) ? 1u : 0u;
+    }
+#pragma unroll
+    for (uint32_t b = 0; b < kBins; b++) counts[b][tid] = local[b];
+    __syncthreads();
+    if (tid < kBins) {  // rank of a thread's first strip inside its class; class size in counts[b][kThreads]
+        uint32_t acc = 0;
+        for (uint32_t t = 0; t < kThreads; t++) { uint32_t c = counts[tid][t]; counts[tid][t] = acc; acc += c; }
+        counts[tid][kThreads] = acc;
+        seglen[tid] = (acc + kLists - 1) / kLists;
+    }
+    __syncthreads();
+    if (tid < kLists) {
+        uint32_t acc = 0;
+        for (int b = kBins - 1; b >= 0; b--) {  // expensive classes first
+            list_base[b][tid] = acc;
+            const uint32_t n = counts[b][kThreads], sl = seglen[b];
+            const uint32_t begin = min(tid * sl, n), end = min(begin + sl, n);
+            acc += end - begin;
+        }
+        sched[tid] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t b = 0; b < kBins; b++) local[b] = counts[b][tid];
+    for (uint32_t s = lo; s < hi; s++) {
+        const uint32_t b = min(cost[s] >> 3, kBins - 1);
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kBins; k++) { rank = (k == b) ? local[k] : rank; local[k] += (k == b) ? 1u : 0u; }
+        const uint32_t sl = seglen[b];
+        const uint32_t list = rank / sl, within = rank - list * sl;
+        sched[kLists + list * cap + list_base[b][list] + within] = s;
+    }
+}
+
+hipError_t launch_strip_feedback(const WorkDesc &work, const svo_hit *hits, uint32_t *cost, uint32_t *order,
+                                 uint32_t n_strips, uint32_t cap, hipStream_t stream) {
+    (void)hipGetLastError();
+    uint32_t blocks = (n_strips + 3u) / 4u;
+    if (blocks > 2048u) blocks = 2048u;
+    hipLaunchKernelGGL(strip_cost_kernel, dim3(blocks), dim3(256), 0, stream, work, hits, cost, n_strips);
+    hipLaunchKernelGGL(strip_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)cost, order, n_strips, cap);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint32_t *top_table, hipStream_t stream) {
+    (void)hipGetLastError();  // drop a stale error left by other users of the runtime in this thread
     const int cells = 1 << (3 * kTopLevels);
     hipLaunchKernelGGL(build_top_table_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream, nodes, n_words,
                        top_table, kTopLevels);
@@ -729,14 +847,15 @@ hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint3
 
 constexpr int kStackBlock = 256;
 constexpr int kStackLevels = 14;
+constexpr int kPoolWordsHost = 14;
 
 int stack_max_depth() { return kTopLevels + 1 + kStackLevels; }
 
 template <bool GE>
 static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
-    const uint32_t strip_items = li.strip_items ? li.strip_items : 64u;
+    const uint32_t strip_items = args.order ? 64u : (li.strip_items ? li.strip_items : 64u);
     auto kern = trace_stack_kernel<kStackBlock, kStackLevels, kTopLevels, GE>;
-    size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + kStackLevels * kStackBlock + (kStackBlock / 64) * kPoolWords * 64) *
+    size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + kStackLevels * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64) *
                        sizeof(uint32_t);
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
@@ -756,8 +875,10 @@ static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipS
 }
 
 hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
+    (void)hipGetLastError();
     if (args.work.n_items == 0) return hipSuccess;
-    if (li.variant == SVO_VARIANT_RESTART) {
+    const bool counter_hits = (args.u.flags & SVO_F_PAUSE_ADAPTIVE) && (args.u.flags & SVO_F_SHOW_HITS);
+    if (li.variant == SVO_VARIANT_RESTART || counter_hits) {  // the debug hit test reads counter bits: general kernel
         uint32_t blocks = (args.work.n_items + 255u) / 256u;
         uint32_t cap = (uint32_t)li.num_cus * 8u;
         if (li.grid_blocks > 0) cap = (uint32_t)li.grid_blocks;
@@ -777,6 +898,7 @@ hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t
 
 hipError_t launch_scan(const uint32_t *nodes, uint32_t n_words, uint32_t node_length, uint32_t *sub, uint32_t *unsub,
                        uint32_t capacity, hipStream_t stream) {
+    (void)hipGetLastError();
     if (n_words == 0) return hipSuccess;
     uint32_t blocks = (n_words + 255u) / 256u;
     if (blocks > 2048u) blocks = 2048u;

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--strip", default="64")
     ap.add_argument("--dynamic", default="1")
     ap.add_argument("--grid", default="0")
+    ap.add_argument("--prio", default="0")
+    ap.add_argument("--schedule", default="1")
     a = ap.parse_args()
     pkg = entry.load_package()
     import torch
@@ -47,10 +49,11 @@ def main():
     hits = render.alloc_hits(a.w * a.h)
     n = a.w * a.h
     ref = None
-    for variant, refill, strip, dyn, grid in itertools.product(
+    for variant, refill, strip, dyn, grid, prio, sched in itertools.product(
             [int(x) for x in a.variants.split(",")], [int(x) for x in a.refill.split(",")],
             [int(x) for x in a.strip.split(",")], [int(x) for x in a.dynamic.split(",")],
-            [int(x) for x in a.grid.split(",")]):
+            [int(x) for x in a.grid.split(",")], [int(x) for x in a.prio.split(",")],
+            [int(x) for x in a.schedule.split(",")]):
         if variant == 0 and (refill, strip, dyn) != (int(a.refill.split(",")[0]), int(a.strip.split(",")[0]), int(a.dynamic.split(",")[0])):
             continue
         gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
@@ -58,6 +61,8 @@ def main():
         gpu.set_option(pkg.gpu.OPT_STRIP_ITEMS, strip)
         gpu.set_option(pkg.gpu.OPT_DYNAMIC_STRIPS, dyn)
         gpu.set_option(pkg.gpu.OPT_GRID_BLOCKS, grid)
+        gpu.set_option(pkg.gpu.OPT_PRIO_STEPS, prio)
+        gpu.set_option(pkg.gpu.OPT_SCHEDULE, sched)
         ms = []
         for i in range(a.reps + 2):
             render.render(hits=hits)
@@ -71,7 +76,7 @@ def main():
             ref = h.copy()
         same = bool(np.array_equal(ref, h))
         med = float(np.median(ms))
-        print(json.dumps({"variant": variant, "refill": refill, "strip": strip, "dynamic": dyn, "grid": grid,
+        print(json.dumps({"variant": variant, "refill": refill, "strip": strip, "dynamic": dyn, "grid": grid, "prio": prio, "schedule": sched,
                           "ms_med": round(med, 4), "ms_min": round(min(ms), 4), "mrays_s": round(n / med / 1e3, 1),
                           "sig": sig, "same_as_first": same}), flush=True)
     steps = (ref[:, 2] & 0xFF)
