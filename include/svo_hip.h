@@ -87,8 +87,9 @@ typedef enum svo_option {
     SVO_OPT_REFILL_MIN = 3,  /* idle lanes needed before a wave refills */
     SVO_OPT_STRIP_ITEMS = 4, /* pixel slots a wave claims at a time (multiple of 64) */
     SVO_OPT_DYNAMIC_STRIPS = 5, /* 1: waves claim strips from device counters; 0: static round-robin */
-    SVO_OPT_SCHEDULE = 8,    /* 1 (default): trace the strips whose rays took the most steps in the previous frame
-                                of the same layout first; 0: screen order.  Results do not depend on it. */
+    SVO_OPT_SCHEDULE = 8,    /* n > 0 (default 4): trace the strips whose rays took the most steps in an earlier frame of
+                                the same layout first, rebuilding that schedule every n frames; 0: screen order.
+                                Results do not depend on it. */
     SVO_OPT_DEBUG_BUFFER = 7, /* device pointer receiving 4 words per wave: start, queue-dry, end (10 ns ticks), rounds */
     SVO_OPT_PRIO_STEPS = 6   /* waves carrying rays with >= this many steps raise their issue priority (0 = off) */
 } svo_option;

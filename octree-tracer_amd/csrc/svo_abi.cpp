@@ -41,9 +41,12 @@ struct svo_ctx {
     uint32_t prio_steps = 0;
     // scheduling feedback (strip order from the previous frame of the same work layout)
     bool schedule = true;
-    uint32_t *sched_cost = nullptr, *sched_order = nullptr;
+    uint8_t *sched_cost = nullptr;
+    uint32_t *sched_order = nullptr;
     size_t sched_cap = 0;
     bool sched_valid = false;
+    uint32_t sched_period = 4, sched_age = 0;  // frames between schedule rebuilds
+    int frame_parity = 0;
     svo::WorkDesc sched_key{};
     uint32_t *debug_buf = nullptr;  // caller-provided device buffer for the per-wave timeline (diagnostics)
     uint32_t strip_items = 64;
@@ -117,16 +120,18 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     a.debug = ctx->debug_buf;
     const bool stack = ctx->variant == SVO_VARIANT_STACK;
     const uint32_t n_strips = (wd.n_items + 63u) / 64u;
-    if (stack && ctx->schedule) {
+    const bool schedule = ctx->schedule && n_strips <= svo::kMaxScheduledStrips;
+    if (stack && schedule) {
         if (ctx->sched_cap < n_strips) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->sched_cost) (void)hipFree(ctx->sched_cost);
             if (ctx->sched_order) (void)hipFree(ctx->sched_order);
-            ctx->sched_cost = ctx->sched_order = nullptr;
+            ctx->sched_cost = nullptr;
+            ctx->sched_order = nullptr;
             ctx->sched_cap = 0;
             ctx->sched_valid = false;
             size_t want = n_strips < 4096 ? 4096 : n_strips;
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->sched_cost, want * sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->sched_cost, want + 16));
             HIP_TRY(ctx, hipMalloc((void **)&ctx->sched_order, (want + 8 * 24 + 8) * sizeof(uint32_t)));
             ctx->sched_cap = want;
         }
@@ -143,17 +148,23 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     if (ctx->variant == SVO_VARIANT_STACK && ctx->defer_items < wd.n_items) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->defer_buf) (void)hipFree(ctx->defer_buf);
-    if (ctx->sched_cost) (void)hipFree(ctx->sched_cost);
-    if (ctx->sched_order) (void)hipFree(ctx->sched_order);
         ctx->defer_buf = nullptr;
+        ctx->frame_parity = 0;
         ctx->defer_items = 0;
         size_t want = wd.n_items < (1u << 16) ? (1u << 16) : wd.n_items;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->defer_buf, (want + svo::kCounterWords + 1) * sizeof(uint32_t)));
+        // layout: claim counters | list A: count + items | list B: count + items
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->defer_buf, (svo::kCounterWords + 2 * (want + 1)) * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->defer_buf, 0, (svo::kCounterWords + 2 * (want + 1)) * sizeof(uint32_t), ctx->stream));
         ctx->defer_items = want;
     }
     li.counters = ctx->defer_buf;
     li.work_counter = ctx->dynamic_strips ? ctx->defer_buf : nullptr;
-    li.defer = ctx->defer_buf ? ctx->defer_buf + svo::kCounterWords : nullptr;
+    if (ctx->defer_buf) {
+        uint32_t *lists = ctx->defer_buf + svo::kCounterWords;
+        const size_t stride = ctx->defer_items + 1;
+        li.defer = lists + (ctx->frame_parity ? stride : 0);
+        li.next_defer_count = lists + (ctx->frame_parity ? 0 : stride);
+    }
     const size_t slot = ctx->ev_slots ? (ctx->ev_count % ctx->ev_slots) : 0;
     if (ctx->ev_slots) HIP_TRY(ctx, hipEventRecord(ctx->ev[2 * slot], ctx->stream));
     HIP_TRY(ctx, svo::launch_trace(a, li, ctx->stream));
@@ -161,12 +172,20 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         HIP_TRY(ctx, hipEventRecord(ctx->ev[2 * slot + 1], ctx->stream));
         ctx->ev_count++;
     }
-    if (stack && ctx->schedule) {
-        // feedback for the next frame: per-strip cost of this frame, sorted most expensive first
-        HIP_TRY(ctx, svo::launch_strip_feedback(wd, hits, ctx->sched_cost, ctx->sched_order, n_strips,
-                                                (n_strips + 7u) / 8u + 16u, ctx->stream));
-        ctx->sched_key = wd;
-        ctx->sched_valid = true;
+    const bool fast_path = stack && !((ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE) && (ctx->uniforms.flags & SVO_F_SHOW_HITS));
+    if (fast_path) {
+        // deferred rays, scheduling feedback for the next frame, counter re-arm
+        const bool rebuild = schedule && (a.order == nullptr || ctx->sched_age + 1 >= ctx->sched_period);
+        HIP_TRY(ctx, svo::launch_post(a, li, rebuild ? ctx->sched_cost : nullptr, ctx->sched_order, n_strips,
+                                      (n_strips + 7u) / 8u + 16u, rebuild, ctx->stream));
+        ctx->frame_parity ^= 1;
+        if (rebuild) {
+            ctx->sched_key = wd;
+            ctx->sched_valid = true;
+            ctx->sched_age = 0;
+        } else if (schedule) {
+            ctx->sched_age++;
+        }
     }
     return SVO_OK;
 }
@@ -297,7 +316,9 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
             ctx->dynamic_strips = value != 0;
             return SVO_OK;
         case SVO_OPT_SCHEDULE:
+            if (value < 0 || value > 1024) return fail(ctx, SVO_ERR_ARG, "schedule period out of range");
             ctx->schedule = value != 0;
+            if (value) ctx->sched_period = (uint32_t)value;
             ctx->sched_valid = false;
             return SVO_OK;
         case SVO_OPT_DEBUG_BUFFER:

@@ -15,12 +15,9 @@ constexpr int kTopEntries = 1 << (3 * kTopLevels);
 constexpr int kPathBits = 24;                  // D: integer path-code bits per axis
 constexpr int kCounterWords = 256;             // 8 claim counters, one per 128-byte line
 
-// Top-table entry (one per level-K cell, index = cx << 2K | cy << K | cz):
-//   bit 31 = 0: bits 0..26 = index of the child group at level K+1 (descent continues there)
-//   bit 31 = 1: a leaf above level K+1: bits 0..26 leaf word index, bits 27..29 depth (1..K),
-//               bit 30 = leaf is solid (pointer - VOXEL_OFFSET > 0)
-constexpr uint32_t kTopLeaf = 0x80000000u;
-constexpr uint32_t kTopSolid = 0x40000000u;
+// Top-table entry (one per level-K cell, index = cx << 2K | cy << K | cz): level << 27 | child group index.
+// The level is K+1 below an interior cell, or the shallower level at which a leaf covers the whole cell
+// (the descent then reads that leaf word itself).
 
 // Work decomposition: a list of equally sized pixel rectangles, each cut into 8x8 pixel blocks.
 // Item q (one pixel slot): rect = q / (64 * blocks_per_rect); block and lane follow.
@@ -59,18 +56,21 @@ struct LaunchInfo {
     int grid_blocks;         // 0 = auto
     int num_cus;
     uint32_t strip_items;    // STACK: pixel slots a wave claims at a time (multiple of 64)
-    uint32_t *counters;      // STACK: kCounterWords + 1 device words zeroed per launch: claim counters, deferred count
+    uint32_t *counters;      // STACK: kCounterWords claim-counter words, zero when a frame starts
     uint32_t *work_counter;  // STACK: counters + 0 for dynamic strip claiming, or nullptr (static round-robin)
-    uint32_t *defer;         // STACK: counters + kCounterWords: count, then one slot per item handed to RESTART
+    uint32_t *defer;         // STACK: this frame's deferred list: count, then one slot per item handed to RESTART
+    uint32_t *next_defer_count;  // STACK: count word of the other list (lists alternate between frames)
 };
 
 hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint32_t *top_table,
                                   hipStream_t stream);
 hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream);
 int stack_max_depth();
-// cost[s] = max step count of strip s in `hits`; order = strips sorted by descending cost
-hipError_t launch_strip_feedback(const WorkDesc &work, const svo_hit *hits, uint32_t *cost, uint32_t *order,
-                                 uint32_t n_strips, uint32_t cap, hipStream_t stream);  // deepest tree level the STACK variant resolves
+// after a STACK trace: deferred rays, per-strip costs (cost != nullptr) and the next schedule; re-arms the counters
+constexpr uint32_t kMaxScheduledStrips = 147456;  // class bytes of one frame must fit the order kernel's LDS (144 KiB)
+hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
+                       uint32_t cap, bool build_schedule, hipStream_t stream);
+
 hipError_t launch_scan(const uint32_t *nodes, uint32_t n_words, uint32_t node_length, uint32_t *sub,
                        uint32_t *unsub, uint32_t capacity, hipStream_t stream);
 

@@ -260,18 +260,19 @@ __global__ __launch_bounds__(256) void build_top_table_kernel(const uint32_t *no
     uint32_t cx = (cell >> (2 * top_levels)) & ((1u << top_levels) - 1u);
     uint32_t cy = (cell >> top_levels) & ((1u << top_levels) - 1u);
     uint32_t cz = cell & ((1u << top_levels) - 1u);
-    uint32_t node_index = 0, entry = 0;
+    // entry = level << 27 | index of the child group to read at that level: level K+1 below an interior cell,
+    // or the (shallower) level whose word is the leaf covering the whole cell
+    uint32_t node_index = 0, entry = ((uint32_t)top_levels + 1u) << 27;
     for (int lvl = 1; lvl <= top_levels; lvl++) {
         int sh = top_levels - lvl;
         uint32_t child = (((cx >> sh) & 1u) << 2) | (((cy >> sh) & 1u) << 1) | ((cz >> sh) & 1u);
-        uint32_t p = node_index + child;
-        uint32_t tn = load_word(rs, p) >> 4;
+        uint32_t tn = load_word(rs, node_index + child) >> 4;
         if (tn >= kVoxelOffset) {
-            entry = kTopLeaf | ((tn != kVoxelOffset) ? kTopSolid : 0u) | ((uint32_t)lvl << 27) | (p & 0x07FFFFFFu);
+            entry = ((uint32_t)lvl << 27) | (node_index & 0x07FFFFFFu);
             break;
         }
         node_index = tn;
-        entry = tn;  // after the last level: child group of level K+1
+        entry = (((uint32_t)top_levels + 1u) << 27) | (tn & 0x07FFFFFFu);
     }
     table[cell] = entry;
 }
@@ -371,9 +372,11 @@ __device__ __forceinline__ bool clean_component(float p, float d) {
 }
 
 // Per-lane state word: bits 0..7 steps | 8..12 leaf depth L | 13..15 step mask (axes of the last step's
-// normal) | 16 normal-is-entry-normal | 19 active | 20 needs descent
+// normal) | 16 normal-is-entry-normal | 19 active | 20 needs descent | 21 record pending | 22..24 how it ended
 constexpr uint32_t ST_L_SHIFT = 8, ST_M_SHIFT = 13;
 constexpr uint32_t ST_ENTRY = 1u << 16, ST_ACTIVE = 1u << 19, ST_DESC = 1u << 20;
+// a finished ray keeps its state until the lane is refilled: record not yet written + how it ended
+constexpr uint32_t ST_PENDING = 1u << 21, ST_F_TOODEEP = 1u << 22, ST_F_SOLID = 1u << 23, ST_F_INB = 1u << 24;
 constexpr uint32_t ST_L_MASK = 31u << ST_L_SHIFT, ST_M_MASK = 7u << ST_M_SHIFT;
 
 // Ray pool: a wave generates the rays of up to 64 work items at once, with every lane busy (lanes that
@@ -472,22 +475,31 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
     uint32_t lvl = 1, nidx = 0;       // next level to read and the child group it lives in
     uint32_t leaf_p = 0, leaf_w = 0;  // current leaf: word index and word
 
-    // leaf words standing in for table hits (only solidity is read from them)
-    constexpr uint32_t kEmptyLeaf = kVoxelOffset << 4, kSolidLeaf = (kVoxelOffset + 1u) << 4;
-
-    // start (or restart) a descent from the top table; leaves met above level K+1 need no descent at all
-    auto from_table = [&]() {
+    // (re)start a descent: from the LDS top table when the restart level r is at most K+1 (the table also
+    // knows leaves that cover a whole level-K cell), else from the lane's ancestor stack.  One LDS read.
+    auto restart_at = [&](uint32_t r) {
+        const bool top = r <= (uint32_t)(K + 1);
         const uint32_t cell = ((uint32_t)(ix >> (D - K)) << (2 * K)) | ((uint32_t)(iy >> (D - K)) << K) |
                               (uint32_t)(iz >> (D - K));
-        const uint32_t t = tbl[cell];
-        if (t & kTopLeaf) {
-            leaf_p = t & 0x07FFFFFFu;
-            leaf_w = (t & kTopSolid) ? kSolidLeaf : kEmptyLeaf;
-            st = (st & ~(ST_L_MASK | ST_DESC)) | (((t >> 27) & 7u) << ST_L_SHIFT);
-        } else {
-            lvl = K + 1;
-            nidx = t;
-        }
+        const uint32_t e = lds[top ? cell : (uint32_t)TBL + (r - SBASE) * BLOCK + tid];
+        lvl = top ? (e >> 27) : r;
+        nidx = e & 0x07FFFFFFu;
+    };
+
+    // write the record of a finished ray (deferred to the next refill so that it runs for many lanes at once)
+    auto flush_record = [&]() {
+        const bool too_deep = (st & ST_F_TOODEEP) != 0u, solid = (st & ST_F_SOLID) != 0u, inb = (st & ST_F_INB) != 0u;
+        const bool stop_here = too_deep || solid;
+        const uint32_t L = (st >> ST_L_SHIFT) & 31u, nm = (st >> ST_M_SHIFT) & 7u;
+        uint32_t c0n = (Dr0 > 0.0f) ? 2u : 1u, c1n = (Dr1 > 0.0f) ? 2u : 1u, c2n = (Dr2 > 0.0f) ? 2u : 1u;
+        uint32_t ncode = ((nm & 1u) ? c0n : 0u) | ((nm & 2u) ? (c1n << 2) : 0u) | ((nm & 4u) ? (c2n << 4) : 0u);
+        if (st & ST_ENTRY) ncode = out >> 26;             // no step taken: the entry normal
+        if (!stop_here && !inb) ncode = 0u;               // left the cube: the miss record carries no normal
+        const uint32_t value = too_deep ? 0xFF000000u : (solid ? leaf_p : (!inb ? 0x20202000u : 0xFF000000u));
+        const uint32_t depth = (too_deep || (!solid && inb)) ? 100u : L;
+        const uint32_t hit = (stop_here || inb) ? 1u : 0u;
+        write_hit(a.hits, out & 0x03FFFFFFu, value, dist + tcur, st & 0xFFu, depth, hit, ncode);
+        st = 0u;
     };
 
     for (;;) {
@@ -559,7 +571,8 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
                     if (next >= strip_end) claim();
                     if (a.debug && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
                 }
-                // -- idle lanes take rays pool_i .. from the pool --
+                // -- idle lanes first write the record of the ray they finished, then take rays pool_i .. --
+                if (st & ST_PENDING) flush_record();
                 if (!(st & ST_ACTIVE)) {
                     const uint64_t idle = ~act;
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
@@ -582,7 +595,7 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
                         iz = (int32_t)pool[13 * 64 + e];
                         tcur = 0.0f;
                         st = ST_ACTIVE | ST_DESC | ST_ENTRY;  // steps = 0, L = 0
-                        from_table();
+                        restart_at(1u);
                     }
                 }
                 const uint32_t took = min(n_idle, pool_n);
@@ -612,17 +625,17 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
             uint32_t off, w;
             uint32_t sh = (uint32_t)D - lvl;                 // bit of the path codes that selects the child
             int32_t rem = (int32_t)SMAX - 1 - (int32_t)lvl;  // < 0 once level SMAX is reached
-            uint32_t sp = (lvl - (uint32_t)(SBASE - 1)) * BLOCK + tid;  // stack slot of level lvl + 1 (lvl >= K + 1)
+            uint32_t sp = (uint32_t)TBL + (lvl - (uint32_t)(SBASE - 1)) * BLOCK + tid;  // slot of level lvl + 1
             for (;;) {
-                const uint32_t child = (__builtin_amdgcn_ubfe((uint32_t)ix, sh, 1u) << 2) |
-                                       (__builtin_amdgcn_ubfe((uint32_t)iy, sh, 1u) << 1) |
-                                       __builtin_amdgcn_ubfe((uint32_t)iz, sh, 1u);
+                uint32_t child = __builtin_amdgcn_ubfe((uint32_t)ix, sh, 1u);
+                child = (child << 1) | __builtin_amdgcn_ubfe((uint32_t)iy, sh, 1u);
+                child = (child << 1) | __builtin_amdgcn_ubfe((uint32_t)iz, sh, 1u);
                 off = (nidx + child) << 2;
                 w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
                 // stop on a leaf (word >= VOXEL_OFFSET << 4 = sign bit) or at level SMAX (deeper trees are refused)
                 if ((int32_t)(w | (uint32_t)rem) < 0) break;
                 nidx = w >> 4;
-                stk[sp] = nidx;
+                lds[sp] = nidx;
                 sp += BLOCK;
                 sh -= 1u;
                 rem -= 1;
@@ -663,26 +676,17 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
             const bool inb = (__builtin_fmaxf(__builtin_fmaxf(G0, G1), G2) < kScale) &&
                              (__builtin_fminf(__builtin_fminf(G0, G1), G2) >= -kScale);
             const bool stop_here = too_deep || solid;         // finish before stepping
-            const uint32_t steps_new = (st & 0xFFu) + 1u;
-            const bool capped = steps_new > 100u;
             const uint32_t mbits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u);
-            if (stop_here || !inb || capped) {
-                if (too_deep) atomicOr(a.status, 1u);
-                // normal of the record: the step just taken (capped), the previous one (solid / too deep) or none (left the cube)
-                uint32_t nm = stop_here ? ((st >> ST_M_SHIFT) & 7u) : mbits;
-                uint32_t c0n = (Dr0 > 0.0f) ? 2u : 1u, c1n = (Dr1 > 0.0f) ? 2u : 1u, c2n = (Dr2 > 0.0f) ? 2u : 1u;
-                uint32_t ncode = ((nm & 1u) ? c0n : 0u) | ((nm & 2u) ? (c1n << 2) : 0u) | ((nm & 4u) ? (c2n << 4) : 0u);
-                if (stop_here && (st & ST_ENTRY)) ncode = out >> 26;
-                uint32_t value = too_deep ? 0xFF000000u : (solid ? leaf_p : (!inb ? 0x20202000u : 0xFF000000u));
-                uint32_t depth = (too_deep || (!solid && inb)) ? 100u : L;
-                uint32_t hit = (stop_here || inb) ? 1u : 0u;
-                if (!stop_here && !inb) ncode = 0u;  // the miss record carries no normal
-                write_hit(a.hits, out & 0x03FFFFFFu, value, dist + (stop_here ? tcur : tnew),
-                          (!stop_here && inb) ? steps_new : (st & 0xFFu), depth, hit, ncode);
-                st = 0u;
-            } else {
+            if (!stop_here) {
+                // the step is taken (its normal, distance and -- if it stays inside -- count are what the record shows)
                 tcur = tnew;
-                st = ((st & ~(ST_M_MASK | ST_ENTRY | 0xFFu)) | (mbits << ST_M_SHIFT) | steps_new) | ST_DESC;
+                st = ((st & ~(ST_M_MASK | ST_ENTRY)) | (mbits << ST_M_SHIFT)) + (inb ? 1u : 0u);
+            }
+            if (stop_here || !inb || (st & 0xFFu) > 100u) {
+                if (too_deep) atomicOr(a.status, 1u);
+                st = (st & ~(ST_ACTIVE | ST_DESC)) | ST_PENDING | (too_deep ? ST_F_TOODEEP : 0u) |
+                     (solid ? ST_F_SOLID : 0u) | (inb ? ST_F_INB : 0u);
+            } else {
                 // new path codes: the position is inside the cube, so no clamping of G
                 int32_t jx, jy, jz;
                 if (GE) {
@@ -698,16 +702,12 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
                 // levels shared by the old and new path: clz over the 24-bit codes (diff == 0: all 24)
                 const uint32_t c = (uint32_t)__clz((int)((diff << 8) | 0x80u));
                 ix = jx; iy = jy; iz = jz;
-                const uint32_t r = min(min(c + 1u, L), (uint32_t)SMAX);
-                if (r <= (uint32_t)(K + 1)) {
-                    from_table();
-                } else {
-                    lvl = r;
-                    nidx = stk[(r - SBASE) * BLOCK + tid];
-                }
+                st |= ST_DESC;
+                restart_at(min(min(c + 1u, L), (uint32_t)SMAX));
             }
         }
     }
+    if (st & ST_PENDING) flush_record();
     if (a.debug && lane == 0) {
         uint64_t t_end = __builtin_amdgcn_s_memrealtime();
         uint32_t *d = a.debug + 4u * wave_id;
@@ -751,20 +751,35 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t *nodes, uint32
 }
 
 // ---------------------------------------------------------------------------------------------
-// Scheduling feedback: cost of every 64-item strip in the frame just traced (the largest step count among
-// its rays) and the strip order for the next frame, most expensive first (counting sort on 0..101).
+// Post pass of a STACK frame (one launch): trace the rays the fast kernel deferred, compute the cost of
+// every 64-item strip (the largest step count among its rays) as scheduling feedback for the next frame,
+// and re-arm the claim counters.  A strip whose deferred rays are written by another workgroup of this
+// launch may see their old records; that only perturbs the schedule, never a result.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void strip_cost_kernel(WorkDesc work, const svo_hit *hits, uint32_t *cost,
-                                                         uint32_t n_strips) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = gridDim.x * 4u;
-    for (uint32_t s = wave; s < n_strips; s += n_waves) {
-        ItemFast it = decode_item_fast(work, s * 64u + lane);
-        uint32_t steps = 0;
-        if (it.valid) steps = reinterpret_cast<const uint4 *>(hits)[it.out].z & 0xFFu;
+__global__ __launch_bounds__(256) void post_kernel(TraceArgs a, uint32_t *claim_counters, const uint32_t *list,
+                                                   uint32_t *next_deferred_count, uint8_t *cost, uint32_t n_strips) {
+    const rsrc_t rs = make_rsrc(a.nodes, a.n_words);
+    const bool misc_bool = (a.u.flags & SVO_F_MISC_BOOL) != 0;
+    // re-arm for the next frame: the claim counters (the trace kernel is done with them) and the deferred
+    // count of the OTHER list (this frame's list is still being read by this launch; lists alternate)
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kCounterWords; i += 256u) claim_counters[i] = 0u;
+        if (threadIdx.x == 0) *next_deferred_count = 0u;
+    }
+    const uint32_t n_def = list[0];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_def; i += gridDim.x * 256u)
+        trace_one_restart(a, rs, misc_bool, false, list[1u + i]);
+    if (cost) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = gridDim.x * 4u;
+        for (uint32_t s = wave; s < n_strips; s += n_waves) {
+            ItemFast it = decode_item_fast(a.work, s * 64u + lane);
+            uint32_t steps = 0;
+            if (it.valid) steps = reinterpret_cast<const uint4 *>(a.hits)[it.out].z & 0xFFu;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, o));
-        if (lane == 0) cost[s] = steps;
+            for (int o = 32; o > 0; o >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, o));
+            if (lane == 0) cost[s] = (uint8_t)min(steps >> 3, 15u);  // cost class
+        }
     }
 }
 
@@ -773,65 +788,76 @@ __global__ __launch_bounds__(256) void strip_cost_kernel(WorkDesc work, const sv
 // segments, one per claim counter (= per XCD, see the kernel).  So every XCD starts its long rays first,
 // gets an equal share of every class, and still walks screen-contiguous runs (node-cache locality).
 // Output: sched[0..7] = entries per list, then 8 lists of `cap` strip numbers each.
-__global__ __launch_bounds__(1024) void strip_order_kernel(const uint32_t *cost, uint32_t *sched, uint32_t n_strips,
+__global__ __launch_bounds__(1024) void strip_order_kernel(const uint8_t *cost_g, uint32_t *sched, uint32_t n_strips,
                                                            uint32_t cap) {
-    constexpr uint32_t kBins = 16, kThreads = 1024, kLists = 8;
-    __shared__ uint32_t counts[kBins][kThreads + 1];  // per class, per thread chunk (exclusive scan in place)
-    __shared__ uint32_t seglen[kBins];                 // strips of a class per list
-    __shared__ uint32_t list_base[kBins][kLists];      // where a class starts inside each list
-    const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = (n_strips + kThreads - 1) / kThreads;
-    const uint32_t lo = min(tid * chunk, n_strips), hi = min(lo + chunk, n_strips);
-    uint32_t local[kBins];
-#pragma unroll
-    for (uint32_t b = 0; b < kBins; b++) local[b] = 0;
-    for (uint32_t s = lo; s < hi; s++) {
-        const uint32_t b = min(cost[s] >> 3, kBins - 1);
-#pragma unroll
-        for (uint32_t k = 0; k < kBins; k++) local[k] += (k == b) ? 1u : 0u;
-    }
-#pragma unroll
-    for (uint32_t b = 0; b < kBins; b++) counts[b][tid] = local[b];
+    constexpr uint32_t kBins = 16, kThreads = 1024, kLists = 8, kWaves = kThreads / 64;
+    extern __shared__ uint32_t cls_words[];          // the class bytes, staged with coalesced loads
+    __shared__ uint32_t wave_tot[kBins][kWaves];     // strips of a class in each wave's range (then: exclusive prefix)
+    __shared__ uint32_t class_n[kBins], seglen[kBins], seg_magic[kBins];
+    __shared__ uint32_t list_base[kBins][kLists];    // where a class starts inside each list
+    const uint8_t *cls = reinterpret_cast<const uint8_t *>(cls_words);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    for (uint32_t i = tid; i < (n_strips + 3u) / 4u; i += kThreads)
+        cls_words[i] = reinterpret_cast<const uint32_t *>(cost_g)[i];
     __syncthreads();
-    if (tid < kBins) {  // rank of a thread's first strip inside its class; class size in counts[b][kThreads]
+    // each wave owns a contiguous range of strips and walks it 64 at a time; lanes 0..15 keep the class tallies
+    const uint32_t per_wave = (((n_strips + kWaves - 1) / kWaves) + 63u) & ~63u;
+    const uint32_t lo = min(wv * per_wave, n_strips), hi = min(lo + per_wave, n_strips);
+    uint32_t tally = 0;
+    for (uint32_t base = lo; base < hi; base += 64u) {
+        const uint32_t s = base + lane;
+        const uint32_t c = s < hi ? cls[s] : 0xFFu;
+        uint64_t todo = __ballot(c != 0xFFu);
+        while (todo) {
+            const uint32_t b = __builtin_amdgcn_readlane(c, __ffsll((unsigned long long)todo) - 1);
+            const uint64_t m = __ballot(c == b);
+            if (lane == b) tally += (uint32_t)__popcll(m);
+            todo &= ~m;
+        }
+    }
+    if (lane < kBins) wave_tot[lane][wv] = tally;
+    __syncthreads();
+    if (tid < kBins) {
         uint32_t acc = 0;
-        for (uint32_t t = 0; t < kThreads; t++) { uint32_t c = counts[tid][t]; counts[tid][t] = acc; acc += c; }
-        counts[tid][kThreads] = acc;
-        seglen[tid] = (acc + kLists - 1) / kLists;
+        for (uint32_t w = 0; w < kWaves; w++) { uint32_t c = wave_tot[tid][w]; wave_tot[tid][w] = acc; acc += c; }
+        class_n[tid] = acc;
+        const uint32_t sl = max((acc + kLists - 1) / kLists, 1u);
+        seglen[tid] = sl;
+        seg_magic[tid] = sl <= 1u ? 0u : (uint32_t)(0x100000000ull / sl) + 1u;
     }
     __syncthreads();
     if (tid < kLists) {
         uint32_t acc = 0;
         for (int b = kBins - 1; b >= 0; b--) {  // expensive classes first
             list_base[b][tid] = acc;
-            const uint32_t n = counts[b][kThreads], sl = seglen[b];
-            const uint32_t begin = min(tid * sl, n), end = min(begin + sl, n);
-            acc += end - begin;
+            const uint32_t n = class_n[b], sl = seglen[b];
+            const uint32_t begin = min(tid * sl, n), endp = min(begin + sl, n);
+            acc += endp - begin;
         }
         sched[tid] = acc;
     }
     __syncthreads();
-#pragma unroll
-    for (uint32_t b = 0; b < kBins; b++) local[b] = counts[b][tid];
-    for (uint32_t s = lo; s < hi; s++) {
-        const uint32_t b = min(cost[s] >> 3, kBins - 1);
+    uint32_t run = lane < kBins ? wave_tot[lane][wv] : 0u;  // rank of the wave's next strip of class `lane`
+    for (uint32_t base = lo; base < hi; base += 64u) {
+        const uint32_t s = base + lane;
+        const uint32_t c = s < hi ? cls[s] : 0xFFu;
+        uint64_t todo = __ballot(c != 0xFFu);
         uint32_t rank = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < kBins; k++) { rank = (k == b) ? local[k] : rank; local[k] += (k == b) ? 1u : 0u; }
-        const uint32_t sl = seglen[b];
-        const uint32_t list = rank / sl, within = rank - list * sl;
-        sched[kLists + list * cap + list_base[b][list] + within] = s;
+        while (todo) {
+            const uint32_t b = __builtin_amdgcn_readlane(c, __ffsll((unsigned long long)todo) - 1);
+            const uint64_t m = __ballot(c == b);
+            const uint32_t first = __builtin_amdgcn_readlane(run, b);
+            if (c == b)
+                rank = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (lane == b) run += (uint32_t)__popcll(m);
+            todo &= ~m;
+        }
+        if (c != 0xFFu) {
+            const uint32_t sl = seglen[c];
+            const uint32_t list = fast_div(rank, sl, seg_magic[c]), within = rank - list * sl;
+            sched[kLists + list * cap + list_base[c][list] + within] = s;
+        }
     }
-}
-
-hipError_t launch_strip_feedback(const WorkDesc &work, const svo_hit *hits, uint32_t *cost, uint32_t *order,
-                                 uint32_t n_strips, uint32_t cap, hipStream_t stream) {
-    (void)hipGetLastError();
-    uint32_t blocks = (n_strips + 3u) / 4u;
-    if (blocks > 2048u) blocks = 2048u;
-    hipLaunchKernelGGL(strip_cost_kernel, dim3(blocks), dim3(256), 0, stream, work, hits, cost, n_strips);
-    hipLaunchKernelGGL(strip_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)cost, order, n_strips, cap);
-    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -886,13 +912,24 @@ hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t
         hipLaunchKernelGGL(trace_restart_kernel, dim3(blocks), dim3(256), 0, stream, args, (const uint32_t *)nullptr);
         return hipGetLastError();
     }
-    // li.counters = {8 region claim counters (128 B apart), deferred-ray count}: zeroed together ahead of the launch
-    hipError_t e = hipMemsetAsync(li.counters, 0, (kCounterWords + 1) * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    e = (args.u.flags & SVO_F_MISC_BOOL) ? launch_stack<true>(args, li, stream) : launch_stack<false>(args, li, stream);
-    if (e != hipSuccess) return e;
-    // rays outside the fast arithmetic's proven range (NaN / inf / extreme magnitudes): reference-shaped kernel
-    hipLaunchKernelGGL(trace_restart_kernel, dim3(16), dim3(256), 0, stream, args, (const uint32_t *)li.defer);
+    // li.counters = {8 claim counters (128 B apart), deferred-ray count, deferred items}: zero when a frame
+    // starts (armed at allocation and re-armed by the last kernel of the previous frame)
+    hipError_t e = (args.u.flags & SVO_F_MISC_BOOL) ? launch_stack<true>(args, li, stream) : launch_stack<false>(args, li, stream);
+    return e;
+}
+
+// After the STACK kernel: deferred rays, per-strip cost classes (cost != nullptr), counter re-arm; and, when
+// `build_schedule`, the strip lists for the next frames.
+hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
+                       uint32_t cap, bool build_schedule, hipStream_t stream) {
+    uint32_t blocks = cost ? (n_strips + 3u) / 4u : 16u;
+    if (blocks > 2048u) blocks = 2048u;
+    if (blocks < 16u) blocks = 16u;
+    hipLaunchKernelGGL(post_kernel, dim3(blocks), dim3(256), 0, stream, args, li.counters, (const uint32_t *)li.defer,
+                       li.next_defer_count, cost, n_strips);
+    if (cost && build_schedule)
+        hipLaunchKernelGGL(strip_order_kernel, dim3(1), dim3(1024), (size_t)((n_strips + 3u) / 4u) * 4u, stream,
+                           (const uint8_t *)cost, sched, n_strips, cap);
     return hipGetLastError();
 }
 

@@ -36,3 +36,8 @@ print("end   us  ", np.percentile(end, pct).round(1))
 print("drain us  ", np.percentile(end - dry, pct).round(1))
 print("rounds    ", np.percentile(d[:, 3], pct).round(0))
 print("us/round  ", np.percentile((end - start) / np.maximum(d[:, 3], 1), pct).round(2))
+idx = np.argsort(end)[-8:]
+print("latest waves: id, dry, end, rounds")
+ids = np.flatnonzero(dbg.cpu().numpy().view(np.uint32)[:, 2] != 0)
+for i in idx:
+    print(int(ids[i]), round(float(dry[i]), 1), round(float(end[i]), 1), int(d[i, 3]))
