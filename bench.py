@@ -90,15 +90,10 @@ def main():
             return hits
     else:
         assert W % tw == 0 and H % th == 0
-        n_pad = pkg.sharding.padded_tile_count(W, H, tw, th, world)
-        local = torch.zeros((n_pad, th * tw, 4), dtype=torch.int32, device=f"cuda:{local_rank}")
-
-        def step():
-            render.render_tiles(tw, th, rank, world, hits=local)
-            g = pkg.sharding.gather_frame(local, rank, world)
-            if rank == 0:
-                return pkg.sharding.assemble_frame(g, W, H, tw, th).contiguous()
-            return None
+        # frame i's RCCL gather overlaps frame i+1's trace (double-buffered); rank 0 un-permutes each frame
+        pipe = pkg.sharding.FramePipeline(lambda buf: render.render_tiles(tw, th, rank, world, hits=buf),
+                                          W, H, tw, th, rank, world, f"cuda:{local_rank}")
+        step = pipe.step
 
     def barrier():
         torch.cuda.synchronize()
@@ -108,11 +103,15 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    if world > 1:
+        pipe.drain()
     barrier()
     gpu.timing_collect()  # drop the warm-up launches' records
     t_start = time.perf_counter()
     for _ in range(a.steps):
         out = step()
+    if world > 1:
+        out = pipe.drain()  # every one of the K frames is gathered and assembled inside the timed region
     barrier()
     elapsed = time.perf_counter() - t_start
     # per-launch kernel durations of exactly the K timed launches: HIP event pairs recorded by the C ABI
@@ -139,7 +138,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
             "config": {"workload": a.workload, "width": W, "height": H, "octree_max_depth": wl["max_depth"],
                        "node_words": int(words.size), "node_bytes": int(words.size) * 4, "rays_per_step": n_rays,
-                       "kernel_variant": "stack", "sharding": "none" if world == 1 else f"tiles {tw}x{th} round-robin + 1 RCCL gather",
+                       "kernel_variant": "stack", "sharding": "none" if world == 1 else f"tiles {tw}x{th} round-robin, 1 RCCL gather per frame overlapped with the next frame's trace",
                        "scene_gen_s": round(gen_s, 1)},
         }
         cpu = None

@@ -118,7 +118,10 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     a.refill_min = ctx->refill_min;
     a.prio_steps = ctx->prio_steps;
     a.debug = ctx->debug_buf;
-    const bool stack = ctx->variant == SVO_VARIANT_STACK;
+    // shader.wgsl:159: counters are live unless pause_adaptive; explicit rays (svo_trace_rays) never count
+    const bool counting = work.mode != 2 && !(ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE);
+    a.count_nodes = counting ? ctx->nodes : nullptr;
+    const bool stack = ctx->variant == SVO_VARIANT_STACK && !counting;
     const uint32_t n_strips = (wd.n_items + 63u) / 64u;
     const bool schedule = ctx->schedule && n_strips <= svo::kMaxScheduledStrips;
     if (stack && schedule) {
@@ -141,11 +144,11 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         a.order_cap = (n_strips + 7u) / 8u + 16u;  // a list holds ceil(n_class / 8) strips of each of the 16 classes
     }
     svo::LaunchInfo li{};
-    li.variant = ctx->variant;
+    li.variant = stack ? SVO_VARIANT_STACK : SVO_VARIANT_RESTART;
     li.grid_blocks = ctx->grid_blocks;
     li.num_cus = ctx->num_cus;
     li.strip_items = ctx->strip_items;
-    if (ctx->variant == SVO_VARIANT_STACK && ctx->defer_items < wd.n_items) {
+    if (stack && ctx->defer_items < wd.n_items) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->defer_buf) (void)hipFree(ctx->defer_buf);
         ctx->defer_buf = nullptr;

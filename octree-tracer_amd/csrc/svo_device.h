@@ -45,6 +45,7 @@ struct TraceArgs {
     uint32_t *rgba;             // may be nullptr
     uint32_t *status;           // device word: bit 0 set when a STACK-variant descent exceeded kPathBits
     uint32_t refill_min;
+    uint32_t *count_nodes;      // writable alias of nodes when hit counters are live (pause_adaptive off), else nullptr
     const uint32_t *order;      // STACK, optional: schedule built by strip_order_kernel (8 lengths + 8 lists)
     uint32_t order_cap;         // entries reserved per list
     uint32_t *debug;            // optional: 4 words per wave (start, queue-dry, end ticks of 10 ns, rounds)

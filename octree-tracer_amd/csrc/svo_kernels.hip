@@ -167,8 +167,22 @@ __device__ __forceinline__ RayIn item_ray(const TraceArgs &a, const Item &it) {
 // Variant RESTART: the reference's algorithm shape -- float-compare descent from the root on
 // every step (shader.wgsl:130-171 inside :213-245), one ray per lane, grid-stride over items.
 // ---------------------------------------------------------------------------------------------
+// Hit-counter side effect of find_voxel (shader.wgsl:157-161): `if (primary && cnt < 15 && !pause_adaptive)
+// n.data[p] = value + 1`.  The reference's plain read-modify-write races between rays; here the increment is a
+// compare-and-swap that stops at 15, so the counters after a frame are min(15, old + visits) whatever the
+// order (the oracle's oracle_count_frame).  Words saturate after 15 visits and are then only read.
+__device__ __forceinline__ void count_visit(uint32_t *nodes, uint32_t n_words, uint32_t p, uint32_t word) {
+    if (p >= n_words) return;
+    while ((word & 15u) < 15u) {
+        const uint32_t seen = atomicCAS(&nodes[p], word, word + 1u);
+        if (seen == word) break;
+        word = seen;
+    }
+}
+
 __device__ __forceinline__ void trace_one_restart(const TraceArgs &a, rsrc_t rs, bool misc_bool, bool counter_hits,
                                                   uint32_t q) {
+    const bool count = a.count_nodes != nullptr;
     Item it = decode_item(a.work, q);
     if (!it.valid) return;
     RayIn r = item_ray(a, it);
@@ -198,6 +212,7 @@ __device__ __forceinline__ void trace_one_restart(const TraceArgs &a, rsrc_t rs,
             c2 = c2 + ((float)bz * 2.0f - 1.0f) / d;
             p = node_index + bx * 4u + by * 2u + bz;
             word = load_word(rs, p);
+            if (count) count_visit(a.count_nodes, a.n_words, p, word);
             uint32_t tn = word >> 4;
             if (tn >= kVoxelOffset) break;
             if (depth >= kMaxDescent) { overflow = true; break; }
@@ -904,7 +919,9 @@ hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t
     (void)hipGetLastError();
     if (args.work.n_items == 0) return hipSuccess;
     const bool counter_hits = (args.u.flags & SVO_F_PAUSE_ADAPTIVE) && (args.u.flags & SVO_F_SHOW_HITS);
-    if (li.variant == SVO_VARIANT_RESTART || counter_hits) {  // the debug hit test reads counter bits: general kernel
+    // the debug hit test reads counter bits, and the adaptive mode writes them for every level of every descent:
+    // both need the reference-shaped walk
+    if (li.variant == SVO_VARIANT_RESTART || counter_hits || args.count_nodes) {
         uint32_t blocks = (args.work.n_items + 255u) / 256u;
         uint32_t cap = (uint32_t)li.num_cus * 8u;
         if (li.grid_blocks > 0) cap = (uint32_t)li.grid_blocks;

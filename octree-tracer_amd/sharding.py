@@ -41,3 +41,47 @@ def assemble_frame(gathered, width, height, tile_w, tile_h):
     # slot-major order is tile order: tile t = k * world + r
     by_tile = gathered.permute(1, 0, 2, 3).reshape(n_pad * world, tile_h, tile_w, 4)[:n]
     return by_tile.reshape(tiles_y, tiles_x, tile_h, tile_w, 4).permute(0, 2, 1, 3, 4).reshape(height, width, 4)
+
+
+class FramePipeline:
+    """Double-buffered frame loop for N > 1 ranks: frame i's gather (RCCL, asynchronous) overlaps frame
+    i+1's trace; rank 0 assembles a frame once its gather has completed.  `trace(buf)` must enqueue the
+    rank's tiles into `buf` ([n_pad, tile_h * tile_w, 4] int32) on the current stream.
+
+    step() returns the most recent COMPLETED frame on rank 0 (None until the first one is ready, and on
+    other ranks); drain() completes what is in flight and returns the last frame."""
+
+    def __init__(self, trace, width, height, tile_w, tile_h, rank, world, device, group=None):
+        self.trace, self.rank, self.world, self.group = trace, rank, world, group
+        self.dims = (width, height, tile_w, tile_h)
+        n_pad = padded_tile_count(width, height, tile_w, tile_h, world)
+        self.local = [torch.zeros((n_pad, tile_h * tile_w, 4), dtype=torch.int32, device=device) for _ in range(2)]
+        self.gathered = [torch.empty((world, n_pad, tile_h * tile_w, 4), dtype=torch.int32, device=device)
+                         if rank == 0 else None for _ in range(2)]
+        self.work = [None, None]
+        self.frame = None
+        self.i = 0
+
+    def _finish(self, b):
+        if self.work[b] is not None:
+            self.work[b].wait()  # the current stream waits for the collective
+            self.work[b] = None
+            if self.rank == 0:
+                self.frame = assemble_frame(self.gathered[b], *self.dims).contiguous()
+
+    def step(self):
+        b = self.i & 1
+        self._finish(b)          # buffer b is free again once frame i-2 has been gathered
+        self.trace(self.local[b])
+        if self.rank == 0:
+            self.work[b] = dist.gather(self.local[b], list(self.gathered[b].unbind(0)), dst=0, group=self.group,
+                                       async_op=True)
+        else:
+            self.work[b] = dist.gather(self.local[b], None, dst=0, group=self.group, async_op=True)
+        self.i += 1
+        return self.frame
+
+    def drain(self):
+        self._finish(self.i & 1)
+        self._finish((self.i + 1) & 1)
+        return self.frame

@@ -224,3 +224,46 @@ def test_error_paths(pkg, gpu):
     with pytest.raises(pkg.SvoError):
         g.set_option(pkg.gpu.OPT_VARIANT, 7)
     g.close()
+
+
+def test_hit_counters_adaptive_mode(pkg, gpu, O, small_words, monu9_words):
+    """pause_adaptive off: every word a primary ray's descent visits gets +1, saturating at 15
+    (shader.wgsl:157-161); the device words after a frame equal the oracle's order-independent count."""
+    for words, size in ((small_words, (96, 64)), (monu9_words, (160, 90))):
+        u = O.make_uniforms(width=size[0], height=size[1], flags=0)  # adaptive on, shadows off
+        render = pkg.Render(gpu, size, words, capacity=words.size + 64)
+        set_uniforms_from_oracle(render, u)
+        hits = pkg.render.hits_to_numpy(render.render())
+        gpu.sync()
+        assert_hits_equal(hits, O.trace_frame(words, u, threads=4), "adaptive-mode hits")
+        want = O.count_frame(words, u)
+        got = render.read_nodes(words.size)
+        assert np.array_equal(got >> 4, words >> 4), "pointers must not change"
+        assert np.array_equal(got, want)
+        # second frame keeps counting from the first frame's state
+        render.render()
+        gpu.sync()
+        assert np.array_equal(render.read_nodes(words.size), O.count_frame(want, u))
+        # the scan then sees the hot leaves (counter >= 4) and the never-visited interior nodes (counter == 0)
+        compute = pkg.Compute(gpu, render)
+        compute.update(int(words.size))
+        sub, unsub = compute.read_lists()
+        now = render.read_nodes(words.size)
+        osub, ounsub = O.scan(now)
+        assert sorted(sub.tolist()) == osub[1:1 + osub[0]].tolist()
+        assert sorted(unsub.tolist()) == ounsub[1:1 + ounsub[0]].tolist()
+        assert osub[0] > 0 or words.size > 1000  # (monu9 leaves are too small to collect 4 visits at this size)
+
+
+def test_debug_show_hits_mode(pkg, gpu, O, small_words):
+    """pause_adaptive && show_hits: the hit test reads the counter bits (shader.wgsl:220-224)."""
+    u0 = O.make_uniforms(width=64, height=64, flags=0)
+    counted = O.count_frame(small_words, u0)
+    u = O.make_uniforms(width=64, height=64, flags=O.F_PAUSE_ADAPTIVE | O.F_SHOW_HITS)
+    render = pkg.Render(gpu, (64, 64), counted, capacity=counted.size)
+    set_uniforms_from_oracle(render, u)
+    for variant in VARIANTS:
+        gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+        got = pkg.render.hits_to_numpy(render.render())
+        gpu.sync()
+        assert_hits_equal(got, O.trace_frame(counted, u, threads=4), "show_hits debug mode")

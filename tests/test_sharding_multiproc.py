@@ -44,12 +44,28 @@ def _worker(rank, world, port, W, H, tw, th, out_path):
             rec = O.trace_frame(words, u, tile=(tx * tw, ty * th, tw, th)).reshape(-1)
             local[k] = torch.from_numpy(rec.view(np.uint32).reshape(-1, 4).view(np.int32).copy())
         g = sh.gather_frame(local, rank, world)
+        ok = True
         if rank == 0:
             frame = sh.assemble_frame(g, W, H, tw, th).contiguous().numpy().view(np.uint32)
             want = O.trace_frame(words, u).reshape(-1).view(np.uint32).reshape(H, W, 4)
-            np.save(out_path, np.array([int(np.array_equal(frame, want))]))
+            ok = bool(np.array_equal(frame, want))
         else:
             assert g is None
+        # the benchmark's double-buffered loop (bench.py, N > 1): three frames through FramePipeline
+        calls = []
+
+        def trace(buf):
+            calls.append(1)
+            buf.copy_(local + len(calls))  # frame k carries records + k, so stale buffers would show
+
+        pipe = sh.FramePipeline(trace, W, H, tw, th, rank, world, "cpu")
+        for k in range(3):
+            done = pipe.step()
+        last = pipe.drain()
+        if rank == 0:
+            got = last.numpy().view(np.uint32)
+            ok = ok and bool(np.array_equal(got, want + np.uint32(3)))
+            np.save(out_path, np.array([int(ok)]))
     finally:
         dist.destroy_process_group()
 
