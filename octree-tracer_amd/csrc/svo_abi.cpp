@@ -39,15 +39,22 @@ struct svo_ctx {
     int grid_blocks = 0;
     uint32_t refill_min = 8;
     uint32_t prio_steps = 0;
-    // scheduling feedback (strip order from the previous frame of the same work layout)
+    // scheduling feedback (strip order from an earlier frame of the same work layout); slot 1: shadow rays
+    struct Sched {
+        uint8_t *cost = nullptr;
+        uint32_t *order = nullptr;
+        size_t cap = 0;
+        bool valid = false;
+        uint32_t age = 0;
+        svo::WorkDesc key{};
+    };
+    Sched sched[2];
     bool schedule = true;
-    uint8_t *sched_cost = nullptr;
-    uint32_t *sched_order = nullptr;
-    size_t sched_cap = 0;
-    bool sched_valid = false;
-    uint32_t sched_period = 4, sched_age = 0;  // frames between schedule rebuilds
+    uint32_t sched_period = 4;  // frames between schedule rebuilds
     int frame_parity = 0;
-    svo::WorkDesc sched_key{};
+    // shading pass scratch (svo_render with rgba_out)
+    void *shade_hits = nullptr, *shade_aux = nullptr, *shade_rays = nullptr, *shade_shadow = nullptr;
+    size_t shade_hits_bytes = 0, shade_aux_bytes = 0, shade_rays_bytes = 0, shade_shadow_bytes = 0;
     uint32_t *debug_buf = nullptr;  // caller-provided device buffer for the per-wave timeline (diagnostics)
     uint32_t strip_items = 64;
     bool dynamic_strips = true;
@@ -89,11 +96,13 @@ int ensure_top_table(svo_ctx *ctx) {
     return SVO_OK;
 }
 
-int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo_hit *hits, uint32_t *rgba) {
-    if (!ctx->nodes) return fail(ctx, SVO_ERR_STATE, "svo_nodes_alloc / svo_nodes_bind_device not called");
-    if (work.mode != 2 && !ctx->have_uniforms) return fail(ctx, SVO_ERR_STATE, "svo_set_uniforms not called");
-    if (!hits) return fail(ctx, SVO_ERR_ARG, "hits_out is NULL");
-    if (rgba) return fail(ctx, SVO_ERR_ARG, "rgba_out: shading kernel not built yet");
+struct TraceOpts {
+    float *aux_t = nullptr;    // t_current per record (shading pass)
+    bool count_rays = false;   // explicit rays also bump hit counters (the shadow ray passes primary = true, shader.wgsl:276)
+    int sched_slot = 0;        // which schedule history this launch feeds (0: primary frame, 1: shadow rays)
+};
+
+int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo_hit *hits, const TraceOpts &opt) {
     int rc = bind(ctx);
     if (rc) return rc;
     if (ctx->variant == SVO_VARIANT_STACK) {
@@ -113,34 +122,33 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     a.work = wd;
     a.rays = rays;
     a.hits = hits;
-    a.rgba = rgba;
+    a.aux_t = opt.aux_t;
     a.status = ctx->status;
     a.refill_min = ctx->refill_min;
     a.prio_steps = ctx->prio_steps;
     a.debug = ctx->debug_buf;
-    // shader.wgsl:159: counters are live unless pause_adaptive; explicit rays (svo_trace_rays) never count
-    const bool counting = work.mode != 2 && !(ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE);
+    // shader.wgsl:159: counters are live unless pause_adaptive; rays handed in by the caller (svo_trace_rays) never count
+    const bool counting = (work.mode != 2 || opt.count_rays) && !(ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE);
     a.count_nodes = counting ? ctx->nodes : nullptr;
-    const bool stack = ctx->variant == SVO_VARIANT_STACK && !counting;
+    const bool debug_hits = (ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE) && (ctx->uniforms.flags & SVO_F_SHOW_HITS);
+    const bool stack = ctx->variant == SVO_VARIANT_STACK && !counting && !debug_hits;
     const uint32_t n_strips = (wd.n_items + 63u) / 64u;
     const bool schedule = ctx->schedule && n_strips <= svo::kMaxScheduledStrips;
+    svo_ctx::Sched &sc = ctx->sched[opt.sched_slot & 1];
     if (stack && schedule) {
-        if (ctx->sched_cap < n_strips) {
+        if (sc.cap < n_strips) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->sched_cost) (void)hipFree(ctx->sched_cost);
-            if (ctx->sched_order) (void)hipFree(ctx->sched_order);
-            ctx->sched_cost = nullptr;
-            ctx->sched_order = nullptr;
-            ctx->sched_cap = 0;
-            ctx->sched_valid = false;
+            if (sc.cost) (void)hipFree(sc.cost);
+            if (sc.order) (void)hipFree(sc.order);
+            sc = svo_ctx::Sched{};
             size_t want = n_strips < 4096 ? 4096 : n_strips;
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->sched_cost, want + 16));
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->sched_order, (want + 8 * 24 + 8) * sizeof(uint32_t)));
-            ctx->sched_cap = want;
+            HIP_TRY(ctx, hipMalloc((void **)&sc.cost, want + 16));
+            HIP_TRY(ctx, hipMalloc((void **)&sc.order, (want + 8 * 24 + 8) * sizeof(uint32_t)));
+            sc.cap = want;
         }
         // the order is only meaningful for the same work layout (same pixels behind every strip)
-        if (ctx->sched_valid && memcmp(&ctx->sched_key, &wd, sizeof(wd)) != 0) ctx->sched_valid = false;
-        a.order = ctx->sched_valid ? ctx->sched_order : nullptr;
+        if (sc.valid && memcmp(&sc.key, &wd, sizeof(wd)) != 0) sc.valid = false;
+        a.order = sc.valid ? sc.order : nullptr;
         a.order_cap = (n_strips + 7u) / 8u + 16u;  // a list holds ceil(n_class / 8) strips of each of the 16 classes
     }
     svo::LaunchInfo li{};
@@ -169,27 +177,87 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         li.next_defer_count = lists + (ctx->frame_parity ? 0 : stride);
     }
     const size_t slot = ctx->ev_slots ? (ctx->ev_count % ctx->ev_slots) : 0;
-    if (ctx->ev_slots) HIP_TRY(ctx, hipEventRecord(ctx->ev[2 * slot], ctx->stream));
+    const bool timed = ctx->ev_slots && opt.sched_slot == 0;  // the timing ring records the primary trace launches
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[2 * slot], ctx->stream));
     HIP_TRY(ctx, svo::launch_trace(a, li, ctx->stream));
-    if (ctx->ev_slots) {
+    if (timed) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[2 * slot + 1], ctx->stream));
         ctx->ev_count++;
     }
-    const bool fast_path = stack && !((ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE) && (ctx->uniforms.flags & SVO_F_SHOW_HITS));
-    if (fast_path) {
-        // deferred rays, scheduling feedback for the next frame, counter re-arm
-        const bool rebuild = schedule && (a.order == nullptr || ctx->sched_age + 1 >= ctx->sched_period);
-        HIP_TRY(ctx, svo::launch_post(a, li, rebuild ? ctx->sched_cost : nullptr, ctx->sched_order, n_strips,
-                                      (n_strips + 7u) / 8u + 16u, rebuild, ctx->stream));
+    if (stack) {
+        // deferred rays, scheduling feedback for the next frames, counter re-arm
+        const bool rebuild = schedule && (a.order == nullptr || sc.age + 1 >= ctx->sched_period);
+        HIP_TRY(ctx, svo::launch_post(a, li, rebuild ? sc.cost : nullptr, sc.order, n_strips, (n_strips + 7u) / 8u + 16u,
+                                      rebuild, ctx->stream));
         ctx->frame_parity ^= 1;
         if (rebuild) {
-            ctx->sched_key = wd;
-            ctx->sched_valid = true;
-            ctx->sched_age = 0;
+            sc.key = wd;
+            sc.valid = true;
+            sc.age = 0;
         } else if (schedule) {
-            ctx->sched_age++;
+            sc.age++;
         }
     }
+    return SVO_OK;
+}
+
+int ensure_dev(svo_ctx *ctx, void **buf, size_t *have, size_t bytes) {
+    if (*have >= bytes) return SVO_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    HIP_TRY(ctx, hipMalloc(buf, bytes));
+    *have = bytes;
+    return SVO_OK;
+}
+
+// Trace (and, when rgba is asked for, shade) the pixels of `work`: fs_main, shader.wgsl:250-304.
+int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo_hit *hits, uint32_t *rgba) {
+    if (!ctx->nodes) return fail(ctx, SVO_ERR_STATE, "svo_nodes_alloc / svo_nodes_bind_device not called");
+    if (work.mode != 2 && !ctx->have_uniforms) return fail(ctx, SVO_ERR_STATE, "svo_set_uniforms not called");
+    if (!hits && !rgba) return fail(ctx, SVO_ERR_ARG, "both hits_out and rgba_out are NULL");
+    if (!rgba) return trace_launch(ctx, work, rays, hits, TraceOpts{});
+    if (work.mode == 2) return fail(ctx, SVO_ERR_ARG, "explicit rays have no pixels to shade");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    const size_t n = (size_t)work.n_rects * work.w * work.h;  // records of this call
+    const uint32_t f = ctx->uniforms.flags;
+    const bool shadows = (f & SVO_F_SHADOWS) && !(f & SVO_F_SHOW_STEPS) && !(f & SVO_F_SHOW_HITS);
+    if (!hits) {
+        rc = ensure_dev(ctx, &ctx->shade_hits, &ctx->shade_hits_bytes, n * sizeof(svo_hit));
+        if (rc) return rc;
+        hits = (svo_hit *)ctx->shade_hits;
+    }
+    rc = ensure_dev(ctx, &ctx->shade_aux, &ctx->shade_aux_bytes, n * sizeof(float));
+    if (rc) return rc;
+    TraceOpts primary;
+    primary.aux_t = (float *)ctx->shade_aux;
+    rc = trace_launch(ctx, work, nullptr, hits, primary);
+    if (rc) return rc;
+    svo::TraceArgs a{};
+    a.nodes = ctx->nodes;
+    a.n_words = (uint32_t)ctx->capacity;
+    a.u = ctx->uniforms;
+    a.work = work;
+    a.hits = hits;
+    if (shadows) {
+        rc = ensure_dev(ctx, &ctx->shade_rays, &ctx->shade_rays_bytes, n * 6 * sizeof(float));
+        if (rc) return rc;
+        rc = ensure_dev(ctx, &ctx->shade_shadow, &ctx->shade_shadow_bytes, n * sizeof(svo_hit));
+        if (rc) return rc;
+        HIP_TRY(ctx, svo::launch_shadow_gen(a, (const float *)ctx->shade_aux, (float *)ctx->shade_rays, ctx->stream));
+        svo::WorkDesc rw{};
+        rw.mode = 2;
+        rw.n_items = (uint32_t)n;
+        rw.bpr = rw.bprect = rw.tiles_x = 1;
+        TraceOpts shadow;
+        shadow.count_rays = true;
+        shadow.sched_slot = 1;
+        rc = trace_launch(ctx, rw, (const float *)ctx->shade_rays, (svo_hit *)ctx->shade_shadow, shadow);
+        if (rc) return rc;
+    }
+    HIP_TRY(ctx, svo::launch_shade(a, shadows ? (const svo_hit *)ctx->shade_shadow : nullptr, rgba, ctx->stream));
     return SVO_OK;
 }
 
@@ -262,8 +330,12 @@ int svo_ctx_destroy(svo_ctx *ctx) {
     if (ctx->top_table) (void)hipFree(ctx->top_table);
     if (ctx->status) (void)hipFree(ctx->status);
     if (ctx->defer_buf) (void)hipFree(ctx->defer_buf);
-    if (ctx->sched_cost) (void)hipFree(ctx->sched_cost);
-    if (ctx->sched_order) (void)hipFree(ctx->sched_order);
+    for (auto &sc : ctx->sched) {
+        if (sc.cost) (void)hipFree(sc.cost);
+        if (sc.order) (void)hipFree(sc.order);
+    }
+    for (void *p : {ctx->shade_hits, ctx->shade_aux, ctx->shade_rays, ctx->shade_shadow})
+        if (p) (void)hipFree(p);
     if (ctx->scan_sub) (void)hipFree(ctx->scan_sub);
     if (ctx->scan_unsub) (void)hipFree(ctx->scan_unsub);
     if (ctx->stage) (void)hipFree(ctx->stage);
@@ -322,7 +394,7 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
             if (value < 0 || value > 1024) return fail(ctx, SVO_ERR_ARG, "schedule period out of range");
             ctx->schedule = value != 0;
             if (value) ctx->sched_period = (uint32_t)value;
-            ctx->sched_valid = false;
+            ctx->sched[0].valid = ctx->sched[1].valid = false;
             return SVO_OK;
         case SVO_OPT_DEBUG_BUFFER:
             ctx->debug_buf = (uint32_t *)(uintptr_t)value;  // device pointer, >= 16 B per wave of the grid; 0 = off
@@ -445,18 +517,21 @@ int svo_render(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t x0, uint3
 int svo_render_host(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t tile_w,
                     uint32_t tile_h, svo_hit *hits_out, uint32_t *rgba_out) {
     if (!ctx) return SVO_ERR_ARG;
-    if (!hits_out) return fail(ctx, SVO_ERR_ARG, "hits_out is NULL");
+    if (!hits_out && !rgba_out) return fail(ctx, SVO_ERR_ARG, "both hits_out and rgba_out are NULL");
     svo::WorkDesc work;
     int rc = make_rect_work(ctx, width, height, x0, y0, tile_w, tile_h, work);
     if (rc) return rc;
     size_t n = (size_t)tile_w * tile_h;
     rc = bind(ctx);
     if (rc) return rc;
-    rc = ensure_stage(ctx, n * sizeof(svo_hit));
+    rc = ensure_stage(ctx, n * (sizeof(svo_hit) + sizeof(uint32_t)));
     if (rc) return rc;
-    rc = trace_common(ctx, work, nullptr, (svo_hit *)ctx->stage, rgba_out ? nullptr : nullptr);
+    svo_hit *dh = (svo_hit *)ctx->stage;
+    uint32_t *dc = (uint32_t *)((char *)ctx->stage + n * sizeof(svo_hit));
+    rc = trace_common(ctx, work, nullptr, dh, rgba_out ? dc : nullptr);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(hits_out, ctx->stage, n * sizeof(svo_hit), hipMemcpyDeviceToHost, ctx->stream));
+    if (hits_out) HIP_TRY(ctx, hipMemcpyAsync(hits_out, dh, n * sizeof(svo_hit), hipMemcpyDeviceToHost, ctx->stream));
+    if (rgba_out) HIP_TRY(ctx, hipMemcpyAsync(rgba_out, dc, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     return svo_sync(ctx);
 }
 

@@ -43,6 +43,7 @@ struct TraceArgs {
     const float *rays;          // mode 2
     svo_hit *hits;              // may be nullptr
     uint32_t *rgba;             // may be nullptr
+    float *aux_t;               // optional: t_current of the last step per record (the shading pass rebuilds HitInfo.pos)
     uint32_t *status;           // device word: bit 0 set when a STACK-variant descent exceeded kPathBits
     uint32_t refill_min;
     uint32_t *count_nodes;      // writable alias of nodes when hit counters are live (pause_adaptive off), else nullptr
@@ -72,6 +73,8 @@ constexpr uint32_t kMaxScheduledStrips = 147456;  // class bytes of one frame mu
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
                        uint32_t cap, bool build_schedule, hipStream_t stream);
 
+hipError_t launch_shadow_gen(const TraceArgs &args, const float *aux_t, float *rays, hipStream_t stream);
+hipError_t launch_shade(const TraceArgs &args, const svo_hit *shadow_hits, uint32_t *rgba, hipStream_t stream);
 hipError_t launch_scan(const uint32_t *nodes, uint32_t n_words, uint32_t node_length, uint32_t *sub,
                        uint32_t *unsub, uint32_t capacity, hipStream_t stream);
 

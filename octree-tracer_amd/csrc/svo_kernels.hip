@@ -189,6 +189,7 @@ __device__ __forceinline__ void trace_one_restart(const TraceArgs &a, rsrc_t rs,
     float pos[3], dir[3], dist;
     if (!ray_enter(r, pos, dir, dist)) {
         write_hit(a.hits, it.out, 0u, 0.0f, 0u, 0u, 0u, 0u);
+        if (a.aux_t) a.aux_t[it.out] = 0.0f;
         return;
     }
     float rs0 = sign_w(dir[0]), rs1 = sign_w(dir[1]), rs2 = sign_w(dir[2]);
@@ -221,11 +222,13 @@ __device__ __forceinline__ void trace_one_restart(const TraceArgs &a, rsrc_t rs,
         uint32_t nc = normal_code(n0) | (normal_code(n1) << 2) | (normal_code(n2) << 4);
         if (overflow) {
             write_hit(a.hits, it.out, 0xFF000000u, dist + t_current, steps, 100u, 1u, nc);
+            if (a.aux_t) a.aux_t[it.out] = t_current;
             return;
         }
         bool solid = counter_hits ? ((word & 15u) > 0u) : (((word >> 4) - kVoxelOffset) > 0u);
         if (solid) {
             write_hit(a.hits, it.out, p, dist + t_current, steps, depth, 1u, nc);
+            if (a.aux_t) a.aux_t[it.out] = t_current;
             return;
         }
         float voxel_size = 2.0f / (float)(1u << depth);
@@ -242,12 +245,14 @@ __device__ __forceinline__ void trace_one_restart(const TraceArgs &a, rsrc_t rs,
         vp2 = pos[2] + dir[2] * t_current - n2 * 0.000002f;
         if (!in_bounds(vp0, vp1, vp2)) {
             write_hit(a.hits, it.out, 0x20202000u, dist + t_current, steps, depth, 0u, 0u);
+            if (a.aux_t) a.aux_t[it.out] = t_current;
             return;
         }
         steps += 1;
         if (steps > 100u) {
             write_hit(a.hits, it.out, 0xFF000000u, dist + t_current, steps, 100u, 1u,
                       normal_code(n0) | (normal_code(n1) << 2) | (normal_code(n2) << 4));
+            if (a.aux_t) a.aux_t[it.out] = t_current;
             return;
         }
     }
@@ -514,6 +519,7 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
         const uint32_t depth = (too_deep || (!solid && inb)) ? 100u : L;
         const uint32_t hit = (stop_here || inb) ? 1u : 0u;
         write_hit(a.hits, out & 0x03FFFFFFu, value, dist + tcur, st & 0xFFu, depth, hit, ncode);
+        if (a.aux_t) a.aux_t[out & 0x03FFFFFFu] = tcur;
         st = 0u;
     };
 
@@ -543,6 +549,7 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
                             float pos[3], dir[3];
                             if (!ray_enter(r, pos, dir, gdist)) {
                                 write_hit(a.hits, it.out, 0u, 0.0f, 0u, 0u, 0u, 0u);
+                                if (a.aux_t) a.aux_t[it.out] = 0.0f;
                             } else if (!(clean_component(pos[0], dir[0]) && clean_component(pos[1], dir[1]) &&
                                          clean_component(pos[2], dir[2]) && fabsf(gdist) <= 1.0e30f)) {
                                 // outside the proven range of the fast arithmetic: hand the ray to the
@@ -873,6 +880,96 @@ __global__ __launch_bounds__(1024) void strip_order_kernel(const uint8_t *cost_g
             sched[kLists + list * cap + list_base[c][list] + within] = s;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fs_main's shading (shader.wgsl:261-304) on top of the hit records.  The shadow ray of :275-280 is traced
+// by the same trace kernels as an explicit ray (svo_trace_rays path): shadow_gen_kernel writes one ray per
+// pixel (a ray that starts outside the cube pointing away -- an immediate miss -- for pixels that need none),
+// the trace kernel produces a second set of records, and shade_kernel combines both into RGBA8.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float code_to_normal(uint32_t c) { return c == 1u ? 1.0f : (c == 2u ? -1.0f : 0.0f); }
+
+__global__ __launch_bounds__(256) void shadow_gen_kernel(TraceArgs a, const float *aux_t, float *rays) {
+    const float sl = sqrtf((a.u.sun_dir[0] * a.u.sun_dir[0] + a.u.sun_dir[1] * a.u.sun_dir[1]) + a.u.sun_dir[2] * a.u.sun_dir[2]);
+    const float s0 = a.u.sun_dir[0] / sl, s1 = a.u.sun_dir[1] / sl, s2 = a.u.sun_dir[2] / sl;  // normalize(u.sun_dir.xyz)
+    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < a.work.n_items; q += gridDim.x * 256u) {
+        Item it = decode_item(a.work, q);
+        if (!it.valid) continue;
+        const uint4 rec = reinterpret_cast<const uint4 *>(a.hits)[it.out];
+        float o[6] = {5.0f, 5.0f, 5.0f, 1.0f, 1.0f, 1.0f};  // never enters the cube
+        if ((rec.z >> 16) & 1u) {
+            RayIn r = gen_ray(a.u, it.px, it.py);
+            float pos[3], dir[3], dist;
+            ray_enter(r, pos, dir, dist);
+            const float n0 = code_to_normal(rec.w & 3u), n1 = code_to_normal((rec.w >> 2) & 3u), n2 = code_to_normal((rec.w >> 4) & 3u);
+            float h0 = pos[0], h1 = pos[1], h2 = pos[2];  // HitInfo.pos = voxel_pos of the last find_voxel
+            if ((rec.z & 0xFFu) != 0u) {
+                const float t = aux_t[it.out];
+                h0 = pos[0] + dir[0] * t - n0 * 0.000002f;
+                h1 = pos[1] + dir[1] * t - n1 * 0.000002f;
+                h2 = pos[2] + dir[2] * t - n2 * 0.000002f;
+            }
+            o[0] = h0 + n0 * 0.0000025f; o[1] = h1 + n1 * 0.0000025f; o[2] = h2 + n2 * 0.0000025f;  // :276
+            o[3] = -s0; o[4] = -s1; o[5] = -s2;
+        }
+        float *dst = rays + 6ull * it.out;
+#pragma unroll
+        for (int k = 0; k < 6; k++) dst[k] = o[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void shade_kernel(TraceArgs a, const svo_hit *shadow_hits, uint32_t *rgba) {
+    const rsrc_t rs = make_rsrc(a.nodes, a.n_words);
+    const float sl = sqrtf((a.u.sun_dir[0] * a.u.sun_dir[0] + a.u.sun_dir[1] * a.u.sun_dir[1]) + a.u.sun_dir[2] * a.u.sun_dir[2]);
+    const float s0 = a.u.sun_dir[0] / sl, s1 = a.u.sun_dir[1] / sl, s2 = a.u.sun_dir[2] / sl;
+    const float gamma = ((a.u.flags & SVO_F_MISC_BOOL) ? 1.0f : 0.0f) * -1.2f + 2.2f;  // :304
+    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < a.work.n_items; q += gridDim.x * 256u) {
+        Item it = decode_item(a.work, q);
+        if (!it.valid) continue;
+        const uint4 rec = reinterpret_cast<const uint4 *>(a.hits)[it.out];
+        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+        const uint32_t word = rec.x < a.n_words ? load_word(rs, rec.x) : 0u;  // sentinel indices read 0
+        if (a.u.flags & SVO_F_SHOW_STEPS) {
+            c0 = c1 = c2 = (float)(rec.z & 0xFFu) / 64.0f;                               // :264
+        } else if ((rec.z >> 16) & 1u) {
+            if (a.u.flags & SVO_F_SHOW_HITS) {
+                c0 = c1 = c2 = (float)(word & 15u) / 15.0f;                              // :268
+            } else {
+                const float n0 = code_to_normal(rec.w & 3u), n1 = code_to_normal((rec.w >> 2) & 3u), n2 = code_to_normal((rec.w >> 4) & 3u);
+                float diffuse = fmax_w((n0 * -s0 + n1 * -s1) + n2 * -s2, 0.0f);         // :273
+                if (shadow_hits && ((reinterpret_cast<const uint4 *>(shadow_hits)[it.out].z >> 16) & 1u)) diffuse = 0.0f;  // :277-279
+                const uint32_t value = (word >> 4) - kVoxelOffset;                       // :282
+                const float k = 0.3f + diffuse;                                          // ambient + diffuse
+                c0 = k * ((float)((value >> 16) & 0xFFu) / 255.0f);
+                c1 = k * ((float)((value >> 8) & 0xFFu) / 255.0f);
+                c2 = k * ((float)(value & 0xFFu) / 255.0f);
+            }
+        } else {
+            c0 = c1 = c2 = 0.2f;                                                         // :287
+        }
+        c0 = powf(fmin_w(fmax_w(c0, 0.0f), 1.0f), gamma);
+        c1 = powf(fmin_w(fmax_w(c1, 0.0f), 1.0f), gamma);
+        c2 = powf(fmin_w(fmax_w(c2, 0.0f), 1.0f), gamma);
+        const uint32_t r8 = (uint32_t)(c0 * 255.0f + 0.5f), g8 = (uint32_t)(c1 * 255.0f + 0.5f), b8 = (uint32_t)(c2 * 255.0f + 0.5f);
+        rgba[it.out] = r8 | (g8 << 8) | (b8 << 16) | (128u << 24);  // alpha 0.5
+    }
+}
+
+hipError_t launch_shadow_gen(const TraceArgs &args, const float *aux_t, float *rays, hipStream_t stream) {
+    (void)hipGetLastError();
+    uint32_t blocks = (args.work.n_items + 255u) / 256u;
+    if (blocks > 4096u) blocks = 4096u;
+    hipLaunchKernelGGL(shadow_gen_kernel, dim3(blocks), dim3(256), 0, stream, args, aux_t, rays);
+    return hipGetLastError();
+}
+
+hipError_t launch_shade(const TraceArgs &args, const svo_hit *shadow_hits, uint32_t *rgba, hipStream_t stream) {
+    (void)hipGetLastError();
+    uint32_t blocks = (args.work.n_items + 255u) / 256u;
+    if (blocks > 4096u) blocks = 4096u;
+    hipLaunchKernelGGL(shade_kernel, dim3(blocks), dim3(256), 0, stream, args, shadow_hits, rgba);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -102,13 +102,20 @@ class Render:
                                               hits.data_ptr(), None))
         return hits
 
-    def render_host(self, tile=None):
-        """Blocking variant with a host result (numpy structured array, tile-local row-major)."""
+    def render_host(self, tile=None, rgba=False):
+        """Blocking variant with host results: hit records (numpy structured array, tile-local row-major)
+        and, with rgba=True, also the shaded RGBA8 image of fs_main (uint8 [h, w, 4])."""
         w, h = self.size
         x0, y0, tw, th = tile if tile is not None else (0, 0, w, h)
         out = np.empty((th, tw), dtype=HIT_DTYPE)
-        self.gpu.check(lib().svo_render_host(self.gpu._h, w, h, x0, y0, tw, th, out.ctypes.data, None))
-        return out
+        img = np.empty((th, tw), dtype=np.uint32) if rgba else None
+        self.gpu.check(lib().svo_render_host(self.gpu._h, w, h, x0, y0, tw, th, out.ctypes.data,
+                                             img.ctypes.data if rgba else None))
+        return (out, img.view(np.uint8).reshape(th, tw, 4)) if rgba else out
+
+    def alloc_rgba(self, n_pixels, device=None):
+        dev = device if device is not None else f"cuda:{self.gpu.device}"
+        return torch.empty((n_pixels,), dtype=torch.int32, device=dev)
 
     def trace_rays(self, rays, hits=None):
         """octree_ray over explicit rays (device float32 tensor n x 6)."""

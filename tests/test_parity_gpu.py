@@ -267,3 +267,44 @@ def test_debug_show_hits_mode(pkg, gpu, O, small_words):
         got = pkg.render.hits_to_numpy(render.render())
         gpu.sync()
         assert_hits_equal(got, O.trace_frame(counted, u, threads=4), "show_hits debug mode")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_shaded_frame(pkg, gpu, O, monu9_words, small_words, variant):
+    """fs_main end to end (shader.wgsl:261-304): ambient + Lambert, shadow ray, gamma, debug views.
+    pow() differs between libm and the GPU, so the RGBA8 image may differ by one code value; the hit
+    records produced on the way stay bit-exact."""
+    F = O
+    cases = [
+        (monu9_words, F.F_PAUSE_ADAPTIVE | F.F_SHADOWS, ((0.1, 0.2, -1.5), (0.0, 0.0, 1.5))),
+        (monu9_words, F.F_PAUSE_ADAPTIVE | F.F_SHADOWS, ((0.02, 0.31, 0.05), (0.3, -0.2, 1.0))),
+        (monu9_words, F.F_PAUSE_ADAPTIVE, ((1.3, 0.9, 1.2), (-1.0, -0.6, -1.0))),
+        (monu9_words, F.F_PAUSE_ADAPTIVE | F.F_SHADOWS | F.F_MISC_BOOL, ((0.1, 0.2, -1.5), (0.0, 0.0, 1.5))),
+        (small_words, F.F_PAUSE_ADAPTIVE | F.F_SHOW_STEPS, ((0.1, 0.2, -1.5), (0.0, 0.0, 1.5))),
+        (small_words, F.F_PAUSE_ADAPTIVE | F.F_SHADOWS, ((0.1, 0.2, -1.5), (0.0, 0.0, 1.5))),
+    ]
+    gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+    for words, flags, pose in cases:
+        u = O.make_uniforms(pos=pose[0], look=pose[1], width=240, height=136, flags=flags)
+        render = pkg.Render(gpu, (240, 136), words, capacity=words.size)
+        set_uniforms_from_oracle(render, u)
+        for frame in range(2):  # the second frame runs with both schedules (primary + shadow rays) in place
+            hits, img = render.render_host(rgba=True)
+        assert_hits_equal(hits, O.trace_frame(words, u, threads=8), f"hits under shading flags={flags}")
+        want = O.shade_frame(words, u, threads=8)
+        want8 = np.floor(np.clip(want, 0, 1) * 255.0 + 0.5).astype(np.int32)
+        diff = np.abs(img.astype(np.int32) - want8)
+        assert diff[..., 3].max() == 0 and (img[..., 3] == 128).all()
+        assert diff.max() <= 1, f"flags={flags}: colour off by {diff.max()}"
+        assert (diff == 0).mean() > 0.98
+        # the shadowed / lit split must agree exactly wherever the lit colour is not black
+        assert img[..., :3].any()
+
+
+def test_shaded_frame_counts_shadow_rays(pkg, gpu, O, small_words):
+    """Adaptive mode + shadows: the shadow ray passes primary = true (shader.wgsl:276), so it bumps counters too."""
+    u = O.make_uniforms(width=80, height=48, flags=O.F_SHADOWS)
+    render = pkg.Render(gpu, (80, 48), small_words, capacity=small_words.size)
+    set_uniforms_from_oracle(render, u)
+    render.render_host(rgba=True)
+    assert np.array_equal(render.read_nodes(small_words.size), O.count_frame(small_words, u))
