@@ -78,6 +78,8 @@ void svo_octree_find_voxel(const svo_octree *o, const float pos[3], int64_t max_
 int svo_octree_expanded(const svo_octree *o, size_t size, uint32_t *out);
 void svo_octree_pos_offset(uint32_t child_index, uint32_t depth, float out[3]);
 size_t svo_octree_holes(const svo_octree *o);
+void svo_octree_set_node(svo_octree *o, size_t index, uint32_t word);   /* octree.nodes[i] = word (adaptive.rs:117) */
+void svo_octree_position(const svo_octree *o, size_t index, float out[3]); /* octree.positions[i] */
 
 /* ---- camera ---- */
 void svo_camera_matrices(const float pos[3], const float look[3], float fov_deg, float width, float height,

@@ -8,6 +8,7 @@ C ABI of libsvo_hip.so:
     octree.Octree      <- src/octree.rs   Octree, Voxel, VOXEL_OFFSET
     cpu_octree.CpuOctree <- src/cpu_octree.rs CpuOctree
     camera.{Character, Settings} <- src/main.rs
+    adaptive           <- src/adaptive.rs  process_subdivision / process_unsubdivision (one-chunk world)
     scenes             deterministic benchmark scene generators (no reference counterpart)
 The package directory name contains a hyphen; import it through __graft_entry__.load_package(),
 which registers it as module `octree_tracer_amd`.
@@ -22,6 +23,7 @@ from .render import Render, HIT_DTYPE, F_PAUSE_ADAPTIVE, F_SHOW_STEPS, F_SHOW_HI
 from .compute import Compute
 from . import scenes
 from . import sharding
+from . import adaptive
 
 __all__ = ["Gpu", "Render", "Compute", "Octree", "CpuOctree", "Voxel", "Uniforms", "Character", "Settings",
-           "SvoError", "VOXEL_OFFSET", "CHUNK_OFFSET", "HIT_DTYPE", "create_node", "camera_matrices", "scenes", "sharding"]
+           "SvoError", "VOXEL_OFFSET", "CHUNK_OFFSET", "HIT_DTYPE", "create_node", "camera_matrices", "scenes", "sharding", "adaptive"]

@@ -51,7 +51,7 @@ HOST_SYMBOLS = [
     "svo_cpu_octree_generate_mips", "svo_vox_parse", "svo_vox_write", "svo_rsvo_write",
     "svo_octree_new", "svo_octree_from_words", "svo_octree_free", "svo_octree_len", "svo_octree_raw_data",
     "svo_octree_get_node", "svo_octree_subdivide", "svo_octree_unsubdivide", "svo_octree_find_voxel",
-    "svo_octree_expanded", "svo_octree_pos_offset", "svo_octree_holes", "svo_camera_matrices",
+    "svo_octree_expanded", "svo_octree_pos_offset", "svo_octree_holes", "svo_octree_set_node", "svo_octree_position", "svo_camera_matrices",
     "svo_gen_terrain", "svo_gen_terrain_height", "svo_gen_fractal", "svo_gen_random", "svo_nodes_max_depth",
 ]
 
@@ -127,6 +127,8 @@ def lib():
     sig("svo_octree_expanded", C.c_int, vp, sz, vp)
     sig("svo_octree_pos_offset", None, u32, u32, fp)
     sig("svo_octree_holes", sz, vp)
+    sig("svo_octree_set_node", None, vp, sz, u32)
+    sig("svo_octree_position", None, vp, sz, fp)
     sig("svo_camera_matrices", None, fp, fp, f32, f32, f32, fp, fp)
     sig("svo_gen_terrain", u64, C.POINTER(TerrainParams), vp, u64)
     sig("svo_gen_terrain_height", C.c_int32, u32, u32, u32, u32)

@@ -442,6 +442,10 @@ size_t svo_octree_len(const svo_octree *o) { return o->nodes.size(); }
 const uint32_t *svo_octree_raw_data(const svo_octree *o) { return o->nodes.data(); }
 uint32_t svo_octree_get_node(const svo_octree *o, size_t index) { return o->nodes[index] >> 4; }
 size_t svo_octree_holes(const svo_octree *o) { return o->hole_stack.size(); }
+void svo_octree_set_node(svo_octree *o, size_t index, uint32_t word) { o->nodes[index] = word; }
+void svo_octree_position(const svo_octree *o, size_t index, float out[3]) {
+    out[0] = o->positions[index].x; out[1] = o->positions[index].y; out[2] = o->positions[index].z;
+}
 
 int svo_octree_subdivide(svo_octree *o, size_t node, const uint8_t mask_rgb[24], uint32_t depth) {
     if ((o->nodes[node] >> 4) < kVoxelOffset) return -1;  // "Node already subdivided!" octree.rs:73-75

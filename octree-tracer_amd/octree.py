@@ -101,6 +101,14 @@ class Octree:
             raise ValueError("expanded(size) smaller than the octree")
         return out
 
+    def set_node(self, index, word):
+        lib().svo_octree_set_node(self._h, index, int(word) & 0xFFFFFFFF)
+
+    def position(self, index):
+        out = (C.c_float * 3)()
+        lib().svo_octree_position(self._h, index, out)
+        return tuple(out)
+
     def hole_count(self):
         return lib().svo_octree_holes(self._h)
 

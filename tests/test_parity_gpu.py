@@ -308,3 +308,49 @@ def test_shaded_frame_counts_shadow_rays(pkg, gpu, O, small_words):
     set_uniforms_from_oracle(render, u)
     render.render_host(rgba=True)
     assert np.array_equal(render.read_nodes(small_words.size), O.count_frame(small_words, u))
+
+
+def test_adaptive_streaming_loop(pkg, gpu, O, monu9_words):
+    """The reference's frame loop with live counters (app.rs:94-118 + adaptive.rs): starting from the 8-word
+    root tree, hot leaves are subdivided from the CPU world and the device tree converges towards the view;
+    every intermediate device tree traces bit-exactly like the oracle on the same words."""
+    from conftest import load_vox_fixture
+    size, xyzi, pal, n, _ = load_vox_fixture("monu9")
+    world = pkg.adaptive.World(pkg.CpuOctree.from_voxels(size, xyzi, pal))
+    octree = world.root_octree()
+    assert len(octree) == 8
+    render = pkg.Render.new(gpu, (160, 96), octree, capacity=200_000)
+    render.set_flags(pause_adaptive=False, shadows=False)
+    compute = pkg.Compute.new(gpu, render)
+    loop = pkg.adaptive.AdaptiveLoop(gpu, render, compute, octree, world)
+    settings, character = pkg.Settings(), pkg.Character()
+    sizes, total_sub = [], 0
+    for frame in range(12):
+        before = octree.raw_data()
+        hits, n_sub, n_unsub = loop.frame(settings, character, deterministic=True)
+        gpu.sync()
+        total_sub += n_sub
+        sizes.append(len(octree))
+        # parity of this frame's records against the oracle on the words the frame was traced on
+        u = O.make_uniforms(width=160, height=96, flags=0)
+        for f in ("camera", "camera_inverse"):
+            getattr(u, f)[:] = list(getattr(render.uniforms, f))
+        assert_hits_equal(pkg.render.hits_to_numpy(hits), O.trace_frame(before, u, threads=4), f"adaptive frame {frame}")
+    assert total_sub > 50 and sizes[-1] > sizes[0] and sizes[-1] % 8 == 0
+    words = octree.raw_data()
+    ptr = words >> 4
+    interior = ptr < pkg.VOXEL_OFFSET
+    assert (ptr[interior] % 8 == 0).all() and (ptr[interior] + 8 <= words.size).all()
+    assert (words & 15 == 0).all()  # host words carry counter 0 (octree.rs:28-30,164-166)
+    # a leaf of the streamed tree shows the world's colour (mip or voxel) at that position and depth
+    rng = np.random.default_rng(1)
+    ptrs, rgb = world.chunk.raw()
+    for p in rng.uniform(-0.9, 0.9, (50, 3)).astype(np.float32):
+        idx, depth, _ = octree.find_voxel(p.tolist())
+        _, cidx, _, _ = world.find_voxel(p.tolist(), depth)
+        c = rgb[cidx]
+        assert ptr[idx] - pkg.VOXEL_OFFSET == (int(c[0]) << 16 | int(c[1]) << 8 | int(c[2]))
+    # pausing freezes the tree (app.rs:97)
+    render.set_flags(pause_adaptive=True)
+    _, n_sub, n_unsub = loop.frame(settings, character)
+    assert (n_sub, n_unsub) == (0, 0) and len(octree) == sizes[-1]
