@@ -39,6 +39,7 @@ struct svo_ctx {
     int grid_blocks = 0;
     uint32_t refill_min = 8;
     uint32_t prio_steps = 0;
+    uint32_t tree_depth = 16;  // caller's bound on the octree depth (the reference's Settings.octree_depth)
     // scheduling feedback (strip order from an earlier frame of the same work layout); slot 1: shadow rays
     struct Sched {
         uint8_t *cost = nullptr;
@@ -156,6 +157,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     li.grid_blocks = ctx->grid_blocks;
     li.num_cus = ctx->num_cus;
     li.strip_items = ctx->strip_items;
+    li.deep_stack = ctx->tree_depth > (uint32_t)svo::stack_max_depth(false);
     if (stack && ctx->defer_items < wd.n_items) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->defer_buf) (void)hipFree(ctx->defer_buf);
@@ -395,6 +397,12 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
             ctx->schedule = value != 0;
             if (value) ctx->sched_period = (uint32_t)value;
             ctx->sched[0].valid = ctx->sched[1].valid = false;
+            return SVO_OK;
+        case SVO_OPT_TREE_DEPTH:
+            if (value < 1 || value > 31) return fail(ctx, SVO_ERR_ARG, "tree depth must be 1..31");
+            ctx->tree_depth = (uint32_t)value;
+            if (value > svo::stack_max_depth(true) && ctx->variant == SVO_VARIANT_STACK)
+                ctx->variant = SVO_VARIANT_RESTART;  // deeper than the integer path codes resolve: general kernel
             return SVO_OK;
         case SVO_OPT_DEBUG_BUFFER:
             ctx->debug_buf = (uint32_t *)(uintptr_t)value;  // device pointer, >= 16 B per wave of the grid; 0 = off

@@ -57,6 +57,7 @@ struct LaunchInfo {
     int variant;
     int grid_blocks;         // 0 = auto
     int num_cus;
+    bool deep_stack;         // STACK: 19-level ancestor stack (trees deeper than 18 levels)
     uint32_t strip_items;    // STACK: pixel slots a wave claims at a time (multiple of 64)
     uint32_t *counters;      // STACK: kCounterWords claim-counter words, zero when a frame starts
     uint32_t *work_counter;  // STACK: counters + 0 for dynamic strip claiming, or nullptr (static round-robin)
@@ -67,7 +68,7 @@ struct LaunchInfo {
 hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint32_t *top_table,
                                   hipStream_t stream);
 hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream);
-int stack_max_depth();
+int stack_max_depth(bool deep);
 // after a STACK trace: deferred rays, per-strip costs (cost != nullptr) and the next schedule; re-arms the counters
 constexpr uint32_t kMaxScheduledStrips = 147456;  // class bytes of one frame must fit the order kernel's LDS (144 KiB)
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,

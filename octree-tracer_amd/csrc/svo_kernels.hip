@@ -984,16 +984,17 @@ hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint3
 }
 
 constexpr int kStackBlock = 256;
-constexpr int kStackLevels = 14;
+constexpr int kStackLevels = 14;      // default: resolves levels up to 3 + 1 + 14 = 18
+constexpr int kStackLevelsDeep = 19;  // deep trees: up to level 23
 constexpr int kPoolWordsHost = 14;
 
-int stack_max_depth() { return kTopLevels + 1 + kStackLevels; }
+int stack_max_depth(bool deep) { return kTopLevels + 1 + (deep ? kStackLevelsDeep : kStackLevels); }
 
-template <bool GE>
+template <bool GE, int NS>
 static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
     const uint32_t strip_items = args.order ? 64u : (li.strip_items ? li.strip_items : 64u);
-    auto kern = trace_stack_kernel<kStackBlock, kStackLevels, kTopLevels, GE>;
-    size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + kStackLevels * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64) *
+    auto kern = trace_stack_kernel<kStackBlock, NS, kTopLevels, GE>;
+    size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + NS * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64) *
                        sizeof(uint32_t);
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
@@ -1028,8 +1029,10 @@ hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t
     }
     // li.counters = {8 claim counters (128 B apart), deferred-ray count, deferred items}: zero when a frame
     // starts (armed at allocation and re-armed by the last kernel of the previous frame)
-    hipError_t e = (args.u.flags & SVO_F_MISC_BOOL) ? launch_stack<true>(args, li, stream) : launch_stack<false>(args, li, stream);
-    return e;
+    const bool ge = (args.u.flags & SVO_F_MISC_BOOL) != 0;
+    if (li.deep_stack)  // trees deeper than kTopLevels + 1 + kStackLevels: more LDS per workgroup, fewer resident waves
+        return ge ? launch_stack<true, kStackLevelsDeep>(args, li, stream) : launch_stack<false, kStackLevelsDeep>(args, li, stream);
+    return ge ? launch_stack<true, kStackLevels>(args, li, stream) : launch_stack<false, kStackLevels>(args, li, stream);
 }
 
 // After the STACK kernel: deferred rays, per-strip cost classes (cost != nullptr), counter re-arm; and, when
