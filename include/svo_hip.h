@@ -140,6 +140,10 @@ int svo_last_render_ms(svo_ctx *ctx, float *ms);
  * ring size; blocks until they have finished and resets the record. */
 int svo_timing_collect(svo_ctx *ctx, float *ms_out, size_t cap, size_t *n_out);
 
+/* Diagnostic for profiling: n_loads single-dword buffer loads over the node buffer, lane i at byte i * stride_bytes
+ * (the trace kernels' access shape), to calibrate hardware byte counters on a known line count. */
+int svo_diag_gather(svo_ctx *ctx, uint32_t stride_bytes, uint32_t n_loads);
+
 /* Counter scan (compute.wgsl).  Lists hold `capacity` words: slot 0 = count, slots 1.. = indices. */
 int svo_scan_dispatch(svo_ctx *ctx, uint32_t node_length);
 int svo_scan_read(svo_ctx *ctx, uint32_t *sub, uint32_t *n_sub, uint32_t *unsub, uint32_t *n_unsub,

@@ -41,7 +41,7 @@ DEVICE_SYMBOLS = [
     "svo_ctx_create", "svo_ctx_destroy", "svo_ctx_set_stream", "svo_set_option", "svo_last_error", "svo_sync",
     "svo_nodes_alloc", "svo_nodes_bind_device", "svo_nodes_write", "svo_nodes_read", "svo_nodes_device_ptr",
     "svo_set_uniforms", "svo_render", "svo_render_host", "svo_render_tiles", "svo_trace_rays",
-    "svo_last_render_ms", "svo_timing_collect", "svo_scan_dispatch", "svo_scan_read",
+    "svo_last_render_ms", "svo_timing_collect", "svo_diag_gather", "svo_scan_dispatch", "svo_scan_read",
 ]
 HOST_SYMBOLS = [
     "svo_cpu_octree_new", "svo_cpu_octree_free", "svo_cpu_octree_len", "svo_cpu_octree_load_file",
@@ -95,6 +95,7 @@ def lib():
     sig("svo_trace_rays", C.c_int, vp, vp, sz, vp)
     sig("svo_last_render_ms", C.c_int, vp, fp)
     sig("svo_timing_collect", C.c_int, vp, fp, sz, C.POINTER(sz))
+    sig("svo_diag_gather", C.c_int, vp, u32, u32)
     sig("svo_scan_dispatch", C.c_int, vp, u32)
     sig("svo_scan_read", C.c_int, vp, vp, C.POINTER(u32), vp, C.POINTER(u32), sz)
     # host data model (include/svo_host.h)

@@ -608,6 +608,16 @@ int svo_timing_collect(svo_ctx *ctx, float *ms_out, size_t cap, size_t *n_out) {
     return SVO_OK;
 }
 
+int svo_diag_gather(svo_ctx *ctx, uint32_t stride_bytes, uint32_t n_loads) {
+    if (!ctx || stride_bytes < 4 || (stride_bytes & 3)) return SVO_ERR_ARG;
+    if (!ctx->nodes) return fail(ctx, SVO_ERR_STATE, "svo_nodes_alloc not called");
+    if ((uint64_t)n_loads * (stride_bytes / 4) > ctx->capacity) return fail(ctx, SVO_ERR_ARG, "pattern exceeds the node buffer");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, svo::launch_diag_gather(ctx->nodes, (uint32_t)ctx->capacity, stride_bytes / 4, n_loads, ctx->status, ctx->stream));
+    return SVO_OK;
+}
+
 int svo_scan_dispatch(svo_ctx *ctx, uint32_t node_length) {
     if (!ctx) return SVO_ERR_ARG;
     if (!ctx->nodes) return fail(ctx, SVO_ERR_STATE, "svo_nodes_alloc not called");

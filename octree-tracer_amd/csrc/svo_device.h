@@ -76,6 +76,8 @@ hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cos
 
 hipError_t launch_shadow_gen(const TraceArgs &args, const float *aux_t, float *rays, hipStream_t stream);
 hipError_t launch_shade(const TraceArgs &args, const svo_hit *shadow_hits, uint32_t *rgba, hipStream_t stream);
+hipError_t launch_diag_gather(const uint32_t *buf, uint32_t n_words, uint32_t stride_words, uint32_t n_loads, uint32_t *sink,
+                              hipStream_t stream);
 hipError_t launch_scan(const uint32_t *nodes, uint32_t n_words, uint32_t node_length, uint32_t *sub,
                        uint32_t *unsub, uint32_t capacity, hipStream_t stream);
 

@@ -973,6 +973,27 @@ hipError_t launch_shade(const TraceArgs &args, const svo_hit *shadow_hits, uint3
 }
 
 // ---------------------------------------------------------------------------------------------
+// Counter calibration (diagnostic, see profiles/README.md): the trace kernels' access pattern -- one
+// buffer_load_dword per lane, every lane on its own cache line -- over a buffer far larger than the caches, so
+// that FETCH_SIZE can be compared with a known number of distinct lines at two strides.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void diag_gather_kernel(const uint32_t *buf, uint32_t n_words, uint32_t stride_words,
+                                                          uint32_t n_loads, uint32_t *sink) {
+    const rsrc_t rs = make_rsrc(buf, n_words);
+    uint32_t acc = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_loads; i += gridDim.x * 256u)
+        acc += load_word(rs, i * stride_words);
+    if (acc == 0x12345678u) *sink = acc;  // keep the loads alive
+}
+
+hipError_t launch_diag_gather(const uint32_t *buf, uint32_t n_words, uint32_t stride_words, uint32_t n_loads, uint32_t *sink,
+                              hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(diag_gather_kernel, dim3(2048), dim3(256), 0, stream, buf, n_words, stride_words, n_loads, sink);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint32_t *top_table, hipStream_t stream) {
