@@ -65,6 +65,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    # the library normally travels prebuilt; build it (rank 0) if it does not
+    lib_path = os.path.join(ROOT, "octree-tracer_amd", "libsvo_hip.so")
+    if not os.path.exists(lib_path) and rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
     pkg = entry.load_package()
     wl = WORKLOADS[a.workload]
     W, H = wl["width"], wl["height"]
