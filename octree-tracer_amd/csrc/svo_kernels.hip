@@ -423,7 +423,7 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
     extern __shared__ uint32_t lds[];
     uint32_t *tbl = lds;                          // TBL entries
     uint32_t *stk = lds + TBL;                    // [NS][BLOCK]
-    uint32_t *pool_all = stk + NS * BLOCK;        // [BLOCK / 64][kPoolWords][64]
+    uint32_t *pool_all = stk + (NS + 1) * BLOCK;  // [BLOCK / 64][kPoolWords][64] (one spare stack row, see the descent)
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -644,25 +644,28 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
 
         // ---- 2. descent: one dependent word per level below the restart level ----
         if (st & ST_DESC) {
-            uint32_t off, w;
+            uint32_t off, w, key;
             uint32_t sh = (uint32_t)D - lvl;                 // bit of the path codes that selects the child
-            int32_t rem = (int32_t)SMAX - 1 - (int32_t)lvl;  // < 0 once level SMAX is reached
-            uint32_t sp = (uint32_t)TBL + (lvl - (uint32_t)(SBASE - 1)) * BLOCK + tid;  // slot of level lvl + 1
-            for (;;) {
+            uint32_t rem = (uint32_t)(SMAX - 1) - lvl;       // wraps below zero (sign bit) once level SMAX is reached
+            // slot of level lvl + 1; a descent that starts on a leaf above level K+1 (from the top table) pushes its
+            // one dead word into row 0, which is rewritten before any restart can read it
+            uint32_t sp = (uint32_t)TBL + (max(lvl, (uint32_t)(SBASE - 1)) - (uint32_t)(SBASE - 1)) * BLOCK + tid;
+            // straight-line body, one exit test: the push also happens on the exiting iteration (it lands in the
+            // slot below the leaf, which no restart reads; the stack has one spare row for an exit at level SMAX)
+            do {
                 uint32_t child = __builtin_amdgcn_ubfe((uint32_t)ix, sh, 1u);
                 child = (child << 1) | __builtin_amdgcn_ubfe((uint32_t)iy, sh, 1u);
                 child = (child << 1) | __builtin_amdgcn_ubfe((uint32_t)iz, sh, 1u);
                 off = (nidx + child) << 2;
                 w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
-                // stop on a leaf (word >= VOXEL_OFFSET << 4 = sign bit) or at level SMAX (deeper trees are refused)
-                if ((int32_t)(w | (uint32_t)rem) < 0) break;
                 nidx = w >> 4;
                 lds[sp] = nidx;
                 sp += BLOCK;
+                key = w | rem;  // sign bit: a leaf (word >= VOXEL_OFFSET << 4) or level SMAX reached (deeper trees are refused)
                 sh -= 1u;
-                rem -= 1;
-            }
-            lvl = (uint32_t)D - sh;
+                rem -= 1u;
+            } while ((int32_t)key >= 0);
+            lvl = (uint32_t)D - 1u - sh;
             leaf_p = off >> 2;
             leaf_w = w;
             st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
@@ -1015,7 +1018,7 @@ template <bool GE, int NS>
 static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
     const uint32_t strip_items = args.order ? 64u : (li.strip_items ? li.strip_items : 64u);
     auto kern = trace_stack_kernel<kStackBlock, NS, kTopLevels, GE>;
-    size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + NS * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64) *
+    size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64) *
                        sizeof(uint32_t);
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
