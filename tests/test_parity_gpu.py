@@ -1,4 +1,6 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -414,3 +416,42 @@ def test_config5_fractal_depth20(pkg, gpu, O):
     finally:
         gpu.set_option(pkg.gpu.OPT_TREE_DEPTH, 16)
         gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+
+
+def test_bench_workload_full_size(pkg, gpu, O):
+    """The benchmark configuration at its full size (depth-16 terrain, ~107 M words, 1920x1080): the whole frame
+    against the oracle, frame-to-frame idempotence under the adaptive schedule, and tile sharding == full frame."""
+    cam, look = pkg.scenes.terrain_camera(0, 16)
+    words = pkg.scenes.terrain(seed=0, max_depth=16, cam=cam, lod_c=1500.0, max_words=125_000_000)
+    assert words.size > 64 * 1024 * 1024  # larger than the 256 MiB Infinity Cache
+    W, H = 1920, 1080
+    render = pkg.Render(gpu, (W, H), words, capacity=words.size)
+    render.set_flags(pause_adaptive=True, shadows=False)
+    render.update(pkg.Settings(fov=90.0), pkg.Character(cam, look))
+    gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+    frames = []
+    for _ in range(3):
+        frames.append(pkg.render.hits_to_numpy(render.render()))
+        gpu.sync()
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
+    u = O.Uniforms()
+    for f in ("camera", "camera_inverse", "dimensions", "sun_dir"):
+        getattr(u, f)[:] = list(getattr(render.uniforms, f))
+    u.flags = render.uniforms.flags
+    want = O.trace_frame(words, u, threads=os.cpu_count() or 8)
+    assert_hits_equal(frames[0], want, "bench workload, full 1080p frame")
+    steps = want["info"].reshape(-1) & 0xFF
+    assert 20 < steps.mean() < 30 and steps.max() == 101
+    # 8-way tile sharding reassembles to the same frame
+    tw, th, world = 64, 8, 8
+    tiles_x = W // tw
+    frame = np.zeros((H, W), dtype=pkg.HIT_DTYPE)
+    for r in range(world):
+        got = pkg.render.hits_to_numpy(render.render_tiles(tw, th, r, world)).reshape(-1, th, tw)
+        gpu.sync()
+        t = r + np.arange(got.shape[0]) * world
+        for k, tt in enumerate(t):
+            ty, tx = divmod(int(tt), tiles_x)
+            frame[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = got[k]
+    assert np.array_equal(frame.reshape(-1).view(np.uint32), want.reshape(-1).view(np.uint32))
