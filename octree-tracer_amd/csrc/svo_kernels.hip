@@ -483,7 +483,7 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
     uint32_t pool_n = 0, pool_i = 0;  // wave-uniform: rays waiting in the pool, index of the first
     // optional per-wave timeline (diagnostic builds of the host set a.debug): start, queue-dry, end in 10 ns ticks
     uint64_t t_begin = 0, t_dry = 0;
-    uint32_t n_rounds = 0;
+    uint32_t n_rounds = 0, dbg_active = 0, dbg_iters = 0, dbg_refills = 0, dbg_gens = 0;
     if (a.debug) t_begin = __builtin_amdgcn_s_memrealtime();
 
     // per-lane ray state
@@ -530,7 +530,9 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
         if (more) {
             uint32_t n_idle = 64u - (uint32_t)__popcll(act);
             if (n_idle >= a.refill_min || act == 0ull) {
+                if (a.debug) dbg_refills += 1;
                 if (pool_n == 0u) {
+                    if (a.debug) dbg_gens += 1;
                     // -- generate the next (up to) 64 rays, all lanes --
                     const uint32_t q = next + lane;
                     bool alive = false;
@@ -634,6 +636,7 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
         }
 
         n_rounds += 1;
+        if (a.debug) dbg_active += (uint32_t)__popcll(__ballot((st & ST_ACTIVE) != 0u));
         // Old rays decide when the kernel ends (a ray is a serial chain of up to 101 dependent rounds, and the
         // last ones drain after the work queue is empty): waves that carry rays past a_prio_steps steps get
         // issue priority over the waves they share a SIMD with.
@@ -653,6 +656,7 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
             // straight-line body, one exit test: the push also happens on the exiting iteration (it lands in the
             // slot below the leaf, which no restart reads; the stack has one spare row for an exit at level SMAX)
             do {
+                if (a.debug) dbg_iters += 1;  // (per lane; lane 0 of the wave reports its own count)
                 uint32_t child = __builtin_amdgcn_ubfe((uint32_t)ix, sh, 1u);
                 child = (child << 1) | __builtin_amdgcn_ubfe((uint32_t)iy, sh, 1u);
                 child = (child << 1) | __builtin_amdgcn_ubfe((uint32_t)iz, sh, 1u);
@@ -735,11 +739,15 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
     if (st & ST_PENDING) flush_record();
     if (a.debug && lane == 0) {
         uint64_t t_end = __builtin_amdgcn_s_memrealtime();
-        uint32_t *d = a.debug + 4u * wave_id;
+        uint32_t *d = a.debug + 8u * wave_id;
         d[0] = (uint32_t)t_begin;
         d[1] = (uint32_t)(t_dry ? t_dry : t_end);
         d[2] = (uint32_t)t_end;
         d[3] = n_rounds;
+        d[4] = dbg_active;   // sum over rounds of active lanes
+        d[5] = dbg_iters;    // descent iterations of lane 0
+        d[6] = dbg_refills;
+        d[7] = dbg_gens;
     }
 }
 

@@ -13,7 +13,7 @@ gpu = pkg.Gpu(0)
 render = pkg.Render(gpu, (W, H), words, capacity=words.size)
 render.set_flags(pause_adaptive=True, shadows=False)
 render.update(pkg.Settings(), pkg.Character(cam, look))
-dbg = torch.zeros((16384, 4), dtype=torch.int32, device="cuda")
+dbg = torch.zeros((16384, 8), dtype=torch.int32, device="cuda")
 hits = render.alloc_hits(W * H)
 for _ in range(3):
     render.render(hits=hits)
@@ -36,6 +36,7 @@ print("end   us  ", np.percentile(end, pct).round(1))
 print("drain us  ", np.percentile(end - dry, pct).round(1))
 print("rounds    ", np.percentile(d[:, 3], pct).round(0))
 print("us/round  ", np.percentile((end - start) / np.maximum(d[:, 3], 1), pct).round(2))
+print("active lanes per round (mean over waves):", (d[:, 4].sum() / d[:, 3].sum()).round(2), " refills/round", (d[:, 6].sum() / d[:, 3].sum()).round(3), " gens", int(d[:, 7].sum()), " total rounds", int(d[:, 3].sum()))
 idx = np.argsort(end)[-8:]
 print("latest waves: id, dry, end, rounds")
 ids = np.flatnonzero(dbg.cpu().numpy().view(np.uint32)[:, 2] != 0)
