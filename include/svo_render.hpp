@@ -1,0 +1,189 @@
+// svo_render.hpp -- C++ host-side mirror of the reference's dispatch API over the C ABI (include/svo_hip.h,
+// include/svo_host.h): the same type and method names, argument meaning and error behaviour as
+//   src/gpu.rs      Gpu::new
+//   src/render.rs   Render::{new, update, render, resize}, Uniforms
+//   src/compute.rs  Compute::{new, update}
+//   src/octree.rs   Octree        src/cpu_octree.rs  CpuOctree      src/main.rs  Settings, Character
+// Where the reference unwraps/panics (gpu.rs:24,39; adaptive.rs:66,124; octree.rs:73-75) these classes throw
+// svo::Error.  Header-only; link against libsvo_hip.so.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "svo_hip.h"
+#include "svo_host.h"
+
+namespace svo {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string &what) : std::runtime_error(what), status(s) {}
+};
+
+struct Voxel {  // octree.rs:7-35
+    uint8_t r = 0, g = 0, b = 0;
+    uint32_t to_cpu_value() const { return (uint32_t(r) << 16) | (uint32_t(g) << 8) | b; }
+    uint32_t to_value() const { return (SVO_VOXEL_OFFSET + to_cpu_value()) << 4; }
+};
+
+struct Settings {  // main.rs:116-120, defaults app.rs:23-27
+    uint32_t octree_depth = 12;
+    float fov = 90.0f;
+    float sensitivity = 0.00005f;
+};
+
+struct Character {  // main.rs:122-137
+    float pos[3] = {0.1f, 0.2f, -1.5f};
+    float look[3] = {0.0f, 0.0f, 1.5f};
+};
+
+class Gpu {  // gpu.rs:3-50 (wgpu instance/adapter/device/queue -> one HIP context + stream)
+  public:
+    explicit Gpu(int device = 0) {
+        int rc = svo_ctx_create(device, &ctx_);
+        if (rc != SVO_OK) throw Error(rc, "svo_ctx_create failed (no usable HIP device?)");
+    }
+    ~Gpu() { svo_ctx_destroy(ctx_); }
+    Gpu(const Gpu &) = delete;
+    Gpu &operator=(const Gpu &) = delete;
+    svo_ctx *ctx() const { return ctx_; }
+    void check(int rc) const {
+        if (rc != SVO_OK) throw Error(rc, svo_last_error(ctx_));
+    }
+    void poll_wait() const { check(svo_sync(ctx_)); }  // device.poll(Maintain::Wait)
+    void set_option(int option, int64_t value) const { check(svo_set_option(ctx_, option, value)); }
+
+  private:
+    svo_ctx *ctx_ = nullptr;
+};
+
+class CpuOctree {  // cpu_octree.rs:17-273
+  public:
+    explicit CpuOctree(uint8_t mask = 0) : t_(svo_cpu_octree_new(mask)) {}
+    static CpuOctree load_file(const std::string &file, uint32_t octree_depth) {  // :113-125, Err(String) -> throw
+        char err[256] = {0};
+        svo_cpu_octree *t = svo_cpu_octree_load_file(file.c_str(), octree_depth, err, sizeof err);
+        if (!t) throw Error(SVO_ERR_ARG, err);
+        return CpuOctree(t);
+    }
+    ~CpuOctree() { svo_cpu_octree_free(t_); }
+    CpuOctree(CpuOctree &&o) noexcept : t_(std::exchange(o.t_, nullptr)) {}
+    CpuOctree(const CpuOctree &) = delete;
+    size_t len() const { return svo_cpu_octree_len(t_); }
+    void put_in_voxel(const float pos[3], Voxel v, uint32_t depth) {
+        const uint8_t rgb[3] = {v.r, v.g, v.b};
+        svo_cpu_octree_put_in_voxel(t_, pos, rgb, depth);
+    }
+    std::vector<uint32_t> to_octree_words() const {  // to_octree(), :233-252
+        std::vector<uint32_t> w(len());
+        svo_cpu_octree_to_octree(t_, w.data());
+        return w;
+    }
+    Voxel generate_mip_tree() {  // world.rs:234-336
+        uint8_t top[3];
+        svo_cpu_octree_generate_mips(t_, top);
+        return Voxel{top[0], top[1], top[2]};
+    }
+    svo_cpu_octree *raw() const { return t_; }
+
+  private:
+    explicit CpuOctree(svo_cpu_octree *t) : t_(t) {}
+    svo_cpu_octree *t_;
+};
+
+class Octree {  // octree.rs:43-162
+  public:
+    explicit Octree(const std::vector<uint32_t> &words) : o_(svo_octree_from_words(words.data(), words.size())) {}
+    explicit Octree(const Voxel (&mask)[8]) {
+        uint8_t rgb[24];
+        for (int i = 0; i < 8; i++) { rgb[3 * i] = mask[i].r; rgb[3 * i + 1] = mask[i].g; rgb[3 * i + 2] = mask[i].b; }
+        o_ = svo_octree_new(rgb);
+    }
+    ~Octree() { svo_octree_free(o_); }
+    Octree(const Octree &) = delete;
+    size_t len() const { return svo_octree_len(o_); }
+    const uint32_t *raw_data() const { return svo_octree_raw_data(o_); }
+    uint32_t get_node(size_t i) const { return svo_octree_get_node(o_, i); }
+    void subdivide(size_t node, const Voxel (&mask)[8], uint32_t depth) {
+        uint8_t rgb[24];
+        for (int i = 0; i < 8; i++) { rgb[3 * i] = mask[i].r; rgb[3 * i + 1] = mask[i].g; rgb[3 * i + 2] = mask[i].b; }
+        if (svo_octree_subdivide(o_, node, rgb, depth) != 0) throw Error(SVO_ERR_STATE, "Node already subdivided!");
+    }
+    bool unsubdivide(size_t node) {
+        int rc = svo_octree_unsubdivide(o_, node);
+        if (rc < 0) throw Error(SVO_ERR_STATE, "Tried to unsubdivide a node without position!");
+        return rc == 0;
+    }
+
+  private:
+    svo_octree *o_;
+};
+
+class Render {  // render.rs:3-285
+  public:
+    static constexpr size_t kDefaultCapacity = 10000000;  // render.rs:53
+    svo_uniforms uniforms{};                              // render.rs:287-322 (bools as flag bits)
+    uint32_t width, height;
+
+    // Render::new: node buffer = octree.expanded(capacity), uniform defaults (render.rs:42-61, 306-321)
+    Render(const Gpu &gpu, uint32_t w, uint32_t h, const uint32_t *words, size_t n_words, size_t capacity = kDefaultCapacity)
+        : width(w), height(h), gpu_(gpu) {
+        gpu_.check(svo_nodes_alloc(gpu_.ctx(), capacity > n_words ? capacity : n_words));
+        write_nodes(words, n_words);
+        const float sun[4] = {-1.7f, -1.0f, 0.8f, 0.0f};
+        for (int i = 0; i < 4; i++) uniforms.sun_dir[i] = sun[i];
+        uniforms.flags = SVO_F_SHADOWS;
+    }
+    Render(const Gpu &gpu, uint32_t w, uint32_t h, const Octree &octree, size_t capacity = kDefaultCapacity)
+        : Render(gpu, w, h, octree.raw_data(), octree.len(), capacity) {}
+    // queue.write_buffer(&node_buffer, 0, nodes) (app.rs:113-118)
+    void write_nodes(const uint32_t *words, size_t n) { gpu_.check(svo_nodes_write(gpu_.ctx(), 0, words, n)); }
+    // Render::resize ignores zero sizes (render.rs:182-189)
+    void resize(uint32_t w, uint32_t h) {
+        if (w > 0 && h > 0) { width = w; height = h; }
+    }
+    // Render::update: camera = proj * look_at_rh, inverse, dimensions; upload (render.rs:191-212)
+    void update(const Settings &settings, const Character &character) {
+        svo_camera_matrices(character.pos, character.look, settings.fov, float(width), float(height), uniforms.camera,
+                            uniforms.camera_inverse);
+        uniforms.dimensions[0] = float(width);
+        uniforms.dimensions[1] = float(height);
+        uniforms.dimensions[2] = uniforms.dimensions[3] = 0.0f;
+        gpu_.check(svo_set_uniforms(gpu_.ctx(), &uniforms));
+    }
+    // Render::render: one pass over every pixel (render.rs:217-284).  Device pointers; asynchronous.
+    void render(svo_hit *hits_dev, uint32_t *rgba_dev = nullptr) {
+        gpu_.check(svo_render(gpu_.ctx(), width, height, 0, 0, width, height, hits_dev, rgba_dev));
+    }
+    // same, results copied to host memory (blocking)
+    void render_host(svo_hit *hits, uint32_t *rgba = nullptr) {
+        gpu_.check(svo_render_host(gpu_.ctx(), width, height, 0, 0, width, height, hits, rgba));
+    }
+
+  private:
+    const Gpu &gpu_;
+};
+
+class Compute {  // compute.rs:6-127 + the read-back of adaptive.rs:12-23, 76-87
+  public:
+    static constexpr size_t kMaxPerFrame = 1024000;  // adaptive.rs:3-4
+    Compute(const Gpu &gpu, const Render &) : gpu_(gpu) {}
+    void update(size_t node_length) { gpu_.check(svo_scan_dispatch(gpu_.ctx(), uint32_t(node_length))); }
+    void update(const Octree &octree) { update(octree.len()); }
+    // (subdivide list, unsubdivide list); counts clamped and the device counters reset like adaptive.rs:22-23
+    std::pair<std::vector<uint32_t>, std::vector<uint32_t>> read_lists() {
+        std::vector<uint32_t> sub(kMaxPerFrame), unsub(kMaxPerFrame);
+        uint32_t ns = 0, nu = 0;
+        gpu_.check(svo_scan_read(gpu_.ctx(), sub.data(), &ns, unsub.data(), &nu, kMaxPerFrame));
+        return {std::vector<uint32_t>(sub.begin() + 1, sub.begin() + 1 + ns),
+                std::vector<uint32_t>(unsub.begin() + 1, unsub.begin() + 1 + nu)};
+    }
+
+  private:
+    const Gpu &gpu_;
+};
+
+}  // namespace svo
