@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--tile-w", type=int, default=64)
     ap.add_argument("--tile-h", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2],
+                    help="N=1 only: 2 = consecutive frames alternate between two HIP streams (the drain of one frame "
+                         "overlaps the next); the default 1 keeps frames serial, which is what roofline.* describes")
     ap.add_argument("--cpu-frac", type=int, default=1, help="cpu_baseline traces the top 1/n of the frame's rows")
     a = ap.parse_args()
 
@@ -88,7 +91,20 @@ def main():
 
     tw, th = a.tile_w, a.tile_h
     n_rays = W * H
-    if world == 1:
+    if world == 1 and a.frames_in_flight == 2:
+        s2 = torch.cuda.Stream()
+        gpu2 = pkg.Gpu(local_rank, stream=s2.cuda_stream)
+        render2 = pkg.Render.share_nodes(gpu2, render)
+        gpu2.set_option(pkg.gpu.OPT_TIMING, max(a.steps, 1))
+        lanes = [(render, render.alloc_hits(n_rays), torch.cuda.current_stream()), (render2, render2.alloc_hits(n_rays), s2)]
+        counter = [0]
+
+        def step():
+            r, h, st = lanes[counter[0] & 1]
+            counter[0] += 1
+            r.render(hits=h)
+            return h
+    elif world == 1:
         hits = render.alloc_hits(n_rays)
 
         def step():
@@ -113,6 +129,8 @@ def main():
         pipe.drain()
     barrier()
     gpu.timing_collect()  # drop the warm-up launches' records
+    if world == 1 and a.frames_in_flight == 2:
+        gpu2.timing_collect()
     t_start = time.perf_counter()
     for _ in range(a.steps):
         out = step()
@@ -123,6 +141,8 @@ def main():
     # per-launch kernel durations of exactly the K timed launches: HIP event pairs recorded by the C ABI
     # around each launch on the launch stream
     kms = gpu.timing_collect()
+    if world == 1 and a.frames_in_flight == 2:
+        kms = np.concatenate([kms, gpu2.timing_collect()])
     assert len(kms) == a.steps
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -144,7 +164,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
             "config": {"workload": a.workload, "width": W, "height": H, "octree_max_depth": wl["max_depth"],
                        "node_words": int(words.size), "node_bytes": int(words.size) * 4, "rays_per_step": n_rays,
-                       "kernel_variant": "stack", "sharding": "none" if world == 1 else f"tiles {tw}x{th} round-robin, 1 RCCL gather per frame overlapped with the next frame's trace",
+                       "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight, "sharding": "none" if world == 1 else f"tiles {tw}x{th} round-robin, 1 RCCL gather per frame overlapped with the next frame's trace",
                        "scene_gen_s": round(gen_s, 1)},
         }
         cpu = None

@@ -36,6 +36,21 @@ class Render:
         self.write_nodes(words)
 
     @classmethod
+    def share_nodes(cls, gpu, other):
+        """A second Render on another context (its own stream) over the SAME device node buffer (zero copy):
+        svo_nodes_bind_device.  Used to keep more than one frame in flight."""
+        self = cls.__new__(cls)
+        self.gpu, self.size = gpu, other.size
+        ptr, cap = C.c_void_p(), C.c_size_t()
+        other.gpu.check(lib().svo_nodes_device_ptr(other.gpu._h, C.byref(ptr), C.byref(cap)))
+        gpu.check(lib().svo_nodes_bind_device(gpu._h, ptr, cap.value))
+        self.capacity, self.node_length = cap.value, other.node_length
+        self.uniforms = Uniforms()
+        C.memmove(C.byref(self.uniforms), C.byref(other.uniforms), C.sizeof(Uniforms))
+        self.upload_uniforms()
+        return self
+
+    @classmethod
     def new(cls, gpu, size, octree, capacity=None):
         words = octree.raw_data() if hasattr(octree, "raw_data") else octree
         return cls(gpu, size, words, capacity)
