@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--tile-w", type=int, default=64)
     ap.add_argument("--tile-h", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: validation mode for boxes with fewer GPUs than ranks -- ranks share the visible GPUs and "
+                         "the gather is staged through host memory (not a performance configuration)")
     ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2],
                     help="N=1 only: 2 = consecutive frames alternate between two HIP streams (the drain of one frame "
                          "overlaps the next); the default 1 keeps frames serial, which is what roofline.* describes")
@@ -63,10 +66,15 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if a.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     # the library normally travels prebuilt; build it (rank 0) if it does not
     lib_path = os.path.join(ROOT, "octree-tracer_amd", "libsvo_hip.so")
@@ -113,8 +121,18 @@ def main():
     else:
         assert W % tw == 0 and H % th == 0
         # frame i's RCCL gather overlaps frame i+1's trace (double-buffered); rank 0 un-permutes each frame
-        pipe = pkg.sharding.FramePipeline(lambda buf: render.render_tiles(tw, th, rank, world, hits=buf),
-                                          W, H, tw, th, rank, world, f"cuda:{local_rank}")
+        if a.backend == "nccl":
+            pipe = pkg.sharding.FramePipeline(lambda buf: render.render_tiles(tw, th, rank, world, hits=buf),
+                                              W, H, tw, th, rank, world, f"cuda:{local_rank}")
+        else:
+            n_pad_v = pkg.sharding.padded_tile_count(W, H, tw, th, world)
+            dev_buf = torch.zeros((n_pad_v, th * tw, 4), dtype=torch.int32, device=f"cuda:{local_rank}")
+
+            def trace_via_host(buf):
+                render.render_tiles(tw, th, rank, world, hits=dev_buf)
+                buf.copy_(dev_buf)  # blocking D2H: validation only
+
+            pipe = pkg.sharding.FramePipeline(trace_via_host, W, H, tw, th, rank, world, "cpu")
         step = pipe.step
 
     def barrier():
@@ -145,7 +163,7 @@ def main():
         kms = np.concatenate([kms, gpu2.timing_collect()])
     assert len(kms) == a.steps
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     gpu.sync()
@@ -164,7 +182,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
             "config": {"workload": a.workload, "width": W, "height": H, "octree_max_depth": wl["max_depth"],
                        "node_words": int(words.size), "node_bytes": int(words.size) * 4, "rays_per_step": n_rays,
-                       "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight, "sharding": "none" if world == 1 else f"tiles {tw}x{th} round-robin, 1 RCCL gather per frame overlapped with the next frame's trace",
+                       "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight, "backend": a.backend if world > 1 else None, "sharding": "none" if world == 1 else f"tiles {tw}x{th} round-robin, 1 RCCL gather per frame overlapped with the next frame's trace",
                        "scene_gen_s": round(gen_s, 1)},
         }
         cpu = None
