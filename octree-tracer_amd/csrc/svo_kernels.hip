@@ -10,8 +10,10 @@
 //     comparisons equals the bits of ceil(pos * 2^23) - 1 + 2^23 (floor(..) + 2^23 for the `>=`
 //     form selected by misc_bool).  A step then re-descends only below the deepest ancestor shared
 //     by the old and the new position (clz of the xor of the path codes), from a per-ray ancestor
-//     stack kept in LDS; the top kTopLevels levels of the tree are folded into a 16 KiB table
-//     staged in LDS; waves are persistent and refill finished lanes (ballot + mbcnt compaction).
+//     stack kept in LDS; the top kTopLevels levels of the tree are folded into a 2 KiB table staged
+//     in LDS; waves are persistent, generate rays 64 at a time into an LDS pool and refill finished
+//     lanes from it (ballot + mbcnt compaction); strips of work are claimed longest-rays-first from
+//     8 XCD-local lists built from the previous frames' step counts.
 //   * node words are read with buffer loads (hardware range check: an index past the buffer
 //     reads 0, the semantics the oracle defines for out-of-range words).
 #include <hip/hip_runtime.h>
@@ -311,15 +313,6 @@ __device__ __forceinline__ int32_t path_code(float v, bool ge_mode) {
     i = i < 0 ? 0 : i;
     i = i > 0x00FFFFFF ? 0x00FFFFFF : i;
     return i;
-}
-
-// Same for a position already known to lie in [-1, 1): no clamping of g needed.
-// ceil(g) - 1 == floor(g) - (g is an integer), so one floor serves both tie-break modes.
-__device__ __forceinline__ int32_t path_code_inb(float v, int32_t gt_adjust) {
-    float g = v * 8388608.0f;
-    float fl = floorf(g);
-    int32_t i = (int32_t)fl + 8388608 - ((fl == g) ? gt_adjust : 0);
-    return i < 0 ? 0 : i;
 }
 
 // n / d for n*d_err < 2^32 with one fix-up step; magic = floor(2^32 / d) + 1 (d >= 2), d == 1 handled by magic 0
@@ -638,8 +631,9 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
         n_rounds += 1;
         if (a.debug) dbg_active += (uint32_t)__popcll(__ballot((st & ST_ACTIVE) != 0u));
         // Old rays decide when the kernel ends (a ray is a serial chain of up to 101 dependent rounds, and the
-        // last ones drain after the work queue is empty): waves that carry rays past a_prio_steps steps get
-        // issue priority over the waves they share a SIMD with.
+        // last ones drain after the work queue is empty): waves that carry rays past a.prio_steps steps get
+        // issue priority over the waves they share a SIMD with.  (Measured: no effect on the benchmark -- in the
+        // drain every wave carries old rays -- so it is off by default.)
         if (a.prio_steps != 0u) {
             const bool old_rays = __ballot((st & ST_ACTIVE) && ((st & 0xFFu) >= a.prio_steps)) != 0ull;
             if (old_rays) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
