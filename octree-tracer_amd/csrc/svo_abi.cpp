@@ -39,6 +39,7 @@ struct svo_ctx {
     int grid_blocks = 0;
     uint32_t refill_min = 8;
     uint32_t prio_steps = 0;
+    uint32_t block_w_log2 = 3;  // 64-pixel blocks of 8x8
     uint32_t tree_depth = 16;  // caller's bound on the octree depth (the reference's Settings.octree_depth)
     // scheduling feedback (strip order from an earlier frame of the same work layout); slot 1: shadow rays
     struct Sched {
@@ -274,8 +275,12 @@ int make_rect_work(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t x0, u
     work = svo::WorkDesc{};
     work.mode = 0;
     work.x0 = x0; work.y0 = y0; work.w = w; work.h = h;
-    work.bpr = (w + 7) / 8;
-    work.bprect = work.bpr * ((h + 7) / 8);
+    work.bw_log2 = ctx->block_w_log2;
+    {
+        const uint32_t bw = 1u << work.bw_log2, bh = 64u >> work.bw_log2;
+        work.bpr = (w + bw - 1) / bw;
+        work.bprect = work.bpr * ((h + bh - 1) / bh);
+    }
     work.n_rects = 1;
     work.tiles_x = 1;
     work.n_items = work.bprect * 64u;
@@ -406,6 +411,10 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
             return SVO_OK;
         case SVO_OPT_DEBUG_BUFFER:
             ctx->debug_buf = (uint32_t *)(uintptr_t)value;  // device pointer, >= 16 B per wave of the grid; 0 = off
+            return SVO_OK;
+        case SVO_OPT_BLOCK_SHAPE:
+            if (value < 0 || value > 6) return fail(ctx, SVO_ERR_ARG, "block width log2 must be 0..6");
+            ctx->block_w_log2 = (uint32_t)value;
             return SVO_OK;
         case SVO_OPT_PRIO_STEPS:
             if (value < 0 || value > 255) return fail(ctx, SVO_ERR_ARG, "prio_steps must be 0..255");
@@ -556,8 +565,12 @@ int svo_render_tiles(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t til
     svo::WorkDesc work{};
     work.mode = 1;
     work.w = tile_w; work.h = tile_h;
-    work.bpr = (tile_w + 7) / 8;
-    work.bprect = work.bpr * ((tile_h + 7) / 8);
+    work.bw_log2 = ctx->block_w_log2;
+    {
+        const uint32_t bw = 1u << work.bw_log2, bh = 64u >> work.bw_log2;
+        work.bpr = (tile_w + bw - 1) / bw;
+        work.bprect = work.bpr * ((tile_h + bh - 1) / bh);
+    }
     work.n_rects = first_tile < tiles ? (tiles - first_tile + tile_stride - 1) / tile_stride : 0;
     work.tiles_x = tiles_x;
     work.first_tile = first_tile;

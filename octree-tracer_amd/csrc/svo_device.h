@@ -19,13 +19,14 @@ constexpr int kCounterWords = 256;             // 8 claim counters, one per 128-
 // The level is K+1 below an interior cell, or the shallower level at which a leaf covers the whole cell
 // (the descent then reads that leaf word itself).
 
-// Work decomposition: a list of equally sized pixel rectangles, each cut into 8x8 pixel blocks.
+// Work decomposition: a list of equally sized pixel rectangles, each cut into 64-pixel blocks (8x8 by default).
 // Item q (one pixel slot): rect = q / (64 * blocks_per_rect); block and lane follow.
 struct WorkDesc {
     uint32_t mode;        // 0: one rectangle at (x0, y0); 1: tiles first_tile + k * tile_stride; 2: explicit rays
     uint32_t x0, y0;      // mode 0 origin
     uint32_t w, h;        // rectangle size in pixels
-    uint32_t bpr;         // 8x8 blocks per rectangle row
+    uint32_t bw_log2;     // pixel blocks are 2^bw_log2 wide and 64 / that high (8x8: 3)
+    uint32_t bpr;         // blocks per rectangle row
     uint32_t bprect;      // blocks per rectangle
     uint32_t n_rects;
     uint32_t tiles_x;     // mode 1: tiles per frame row

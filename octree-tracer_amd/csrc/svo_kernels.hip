@@ -141,7 +141,7 @@ __device__ __forceinline__ Item decode_item(const WorkDesc &w, uint32_t q) {
     uint32_t rect = blk / w.bprect;
     uint32_t b = blk - rect * w.bprect;
     uint32_t by = b / w.bpr, bx = b - by * w.bpr;
-    uint32_t x = bx * 8u + (lane & 7u), y = by * 8u + (lane >> 3);
+    uint32_t x = (bx << w.bw_log2) + (lane & ((1u << w.bw_log2) - 1u)), y = (by << (6u - w.bw_log2)) + (lane >> w.bw_log2);
     it.valid = (q < w.n_items) && (x < w.w) && (y < w.h);
     it.out = rect * (w.w * w.h) + y * w.w + x;
     uint32_t ox = w.x0, oy = w.y0;
@@ -343,7 +343,7 @@ __device__ __forceinline__ ItemFast decode_item_fast(const WorkDesc &w, uint32_t
         b = blk - rect * w.bprect;
     }
     uint32_t by = fast_div(b, w.bpr, w.magic_bpr), bx = b - by * w.bpr;
-    uint32_t x = bx * 8u + (lane & 7u), y = by * 8u + (lane >> 3);
+    uint32_t x = (bx << w.bw_log2) + (lane & ((1u << w.bw_log2) - 1u)), y = (by << (6u - w.bw_log2)) + (lane >> w.bw_log2);
     it.valid = (q < w.n_items) && (x < w.w) && (y < w.h);
     it.out = rect * (w.w * w.h) + y * w.w + x;
     uint32_t ox = w.x0, oy = w.y0;

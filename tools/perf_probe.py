@@ -28,7 +28,8 @@ def main():
     ap.add_argument("--dynamic", default="1")
     ap.add_argument("--grid", default="0")
     ap.add_argument("--prio", default="0")
-    ap.add_argument("--schedule", default="1")
+    ap.add_argument("--schedule", default="8")
+    ap.add_argument("--block", default="3")
     a = ap.parse_args()
     pkg = entry.load_package()
     import torch
@@ -49,7 +50,8 @@ def main():
     hits = render.alloc_hits(a.w * a.h)
     n = a.w * a.h
     ref = None
-    for variant, refill, strip, dyn, grid, prio, sched in itertools.product(
+    for blockw, variant, refill, strip, dyn, grid, prio, sched in itertools.product(
+            [int(x) for x in a.block.split(",")],
             [int(x) for x in a.variants.split(",")], [int(x) for x in a.refill.split(",")],
             [int(x) for x in a.strip.split(",")], [int(x) for x in a.dynamic.split(",")],
             [int(x) for x in a.grid.split(",")], [int(x) for x in a.prio.split(",")],
@@ -63,6 +65,7 @@ def main():
         gpu.set_option(pkg.gpu.OPT_GRID_BLOCKS, grid)
         gpu.set_option(pkg.gpu.OPT_PRIO_STEPS, prio)
         gpu.set_option(pkg.gpu.OPT_SCHEDULE, sched)
+        gpu.set_option(pkg.gpu.OPT_BLOCK_SHAPE, blockw)
         ms = []
         for i in range(a.reps + 2):
             render.render(hits=hits)
@@ -76,7 +79,7 @@ def main():
             ref = h.copy()
         same = bool(np.array_equal(ref, h))
         med = float(np.median(ms))
-        print(json.dumps({"variant": variant, "refill": refill, "strip": strip, "dynamic": dyn, "grid": grid, "prio": prio, "schedule": sched,
+        print(json.dumps({"variant": variant, "refill": refill, "strip": strip, "dynamic": dyn, "grid": grid, "prio": prio, "schedule": sched, "block": blockw,
                           "ms_med": round(med, 4), "ms_min": round(min(ms), 4), "mrays_s": round(n / med / 1e3, 1),
                           "sig": sig, "same_as_first": same}), flush=True)
     steps = (ref[:, 2] & 0xFF)
