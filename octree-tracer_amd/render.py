@@ -107,14 +107,15 @@ class Render:
                                         rgba.data_ptr() if rgba is not None else None))
         return hits
 
-    def render_tiles(self, tile_w, tile_h, first_tile, tile_stride, hits=None):
+    def render_tiles(self, tile_w, tile_h, first_tile, tile_stride, hits=None, rgba=None):
+        """This rank's tiles (first_tile, first_tile + tile_stride, ...), contiguous in that order."""
         w, h = self.size
         n_tiles_total = (w // tile_w) * (h // tile_h)
         n_mine = max(0, (n_tiles_total - first_tile + tile_stride - 1) // tile_stride)
         if hits is None:
             hits = self.alloc_hits(n_mine * tile_w * tile_h)
         self.gpu.check(lib().svo_render_tiles(self.gpu._h, w, h, tile_w, tile_h, first_tile, tile_stride,
-                                              hits.data_ptr(), None))
+                                              hits.data_ptr(), rgba.data_ptr() if rgba is not None else None))
         return hits
 
     def render_host(self, tile=None, rgba=False):

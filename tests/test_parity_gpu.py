@@ -455,3 +455,25 @@ def test_bench_workload_full_size(pkg, gpu, O):
             ty, tx = divmod(int(tt), tiles_x)
             frame[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = got[k]
     assert np.array_equal(frame.reshape(-1).view(np.uint32), want.reshape(-1).view(np.uint32))
+
+
+def test_shaded_tiles_match_full_frame(pkg, gpu, O, monu9_words):
+    """svo_render_tiles with rgba_out: the sharded, shaded image equals the unsharded one pixel for pixel."""
+    W, H, tw, th, ranks = 192, 96, 64, 8, 3
+    u = O.make_uniforms(width=W, height=H, flags=O.F_PAUSE_ADAPTIVE | O.F_SHADOWS)
+    render = pkg.Render(gpu, (W, H), monu9_words, capacity=monu9_words.size)
+    set_uniforms_from_oracle(render, u)
+    _, full = render.render_host(rgba=True)
+    full = full.view(np.uint32).reshape(H, W)
+    tiles_x = W // tw
+    img = np.zeros((H, W), dtype=np.uint32)
+    for r in range(ranks):
+        n = pkg.sharding.local_tile_count(W, H, tw, th, r, ranks)
+        rgba = render.alloc_rgba(n * tw * th)
+        render.render_tiles(tw, th, r, ranks, rgba=rgba)
+        gpu.sync()
+        got = rgba.cpu().numpy().view(np.uint32).reshape(n, th, tw)
+        for k in range(n):
+            ty, tx = divmod(r + k * ranks, tiles_x)
+            img[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = got[k]
+    assert np.array_equal(img, full)
