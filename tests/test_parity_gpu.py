@@ -477,3 +477,40 @@ def test_shaded_tiles_match_full_frame(pkg, gpu, O, monu9_words):
             ty, tx = divmod(r + k * ranks, tiles_x)
             img[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = got[k]
     assert np.array_equal(img, full)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_lattice_rays_ties_and_boundaries(pkg, gpu, O, monu9_words, variant):
+    """Rays built to land exactly on cell boundaries and to tie in t_max (several axes in the step mask,
+    shader.wgsl:231): origins on dyadic lattice points, directions along axes, face and space diagonals with
+    exactly equal components, both tie-break modes (shader.wgsl:138-150)."""
+    import itertools
+    import torch
+    trees = [monu9_words, pkg.scenes.random_tree(seed=11, max_depth=7, p_split=0.6, p_solid=0.3, max_words=1 << 19)]
+    dirs = []
+    for d in itertools.product((-1.0, 0.0, 1.0), repeat=3):
+        if any(d):
+            v = np.array(d, dtype=np.float32)
+            dirs.append(v / np.float32(np.sqrt(np.float32((v * v).sum()))))  # equal components stay bit-equal
+    dirs = np.array(dirs, dtype=np.float32)
+    rng = np.random.default_rng(31)
+    for m in (2, 4, 7):
+        k = rng.integers(-(1 << m), (1 << m) + 1, (3000, 3)).astype(np.float32) / np.float32(1 << m)
+        # a third of the origins sit on cell centres (odd multiples of 2^-(m+1)), a few outside the cube
+        k[::3] += np.float32(1.0 / (1 << (m + 1)))
+        k[::50] *= np.float32(1.5)
+        d = dirs[rng.integers(0, len(dirs), k.shape[0])]
+        rays = np.concatenate([k, d], axis=1).astype(np.float32)
+        for words in trees:
+            render = pkg.Render(gpu, (8, 8), words, capacity=words.size)
+            gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+            for flags in (O.F_PAUSE_ADAPTIVE, O.F_PAUSE_ADAPTIVE | O.F_MISC_BOOL):
+                render.uniforms.flags = flags
+                render.upload_uniforms()
+                got = pkg.render.hits_to_numpy(render.trace_rays(torch.from_numpy(rays).cuda()))
+                gpu.sync()
+                want = O.trace_rays(words, rays, flags=flags, threads=8)
+                assert_hits_equal(got, want, f"lattice rays m={m} flags={flags}")
+                multi = np.isin(want["normal_bits"], [0b000101, 0b000110, 0b001001, 0b001010, 0b010001, 0b010010,
+                                                      0b100001, 0b100010, 0b010100, 0b011000, 0b100100, 0b101000])
+                assert multi.any(), "the set should contain steps that tie on two axes"
