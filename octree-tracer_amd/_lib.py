@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvo_hip.so")
+LIB_PATH = os.environ.get("SVO_HIP_LIB") or os.path.join(_HERE, "libsvo_hip.so")  # override: A/B builds in experiments
 
 
 class Uniforms(C.Structure):

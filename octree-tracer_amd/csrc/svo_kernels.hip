@@ -483,6 +483,7 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
     uint32_t st = 0;                  // packed, see ST_*
     uint32_t out = 0;                 // bits 0..25 output index, 26..31 entry normal code
     float P0 = 0, P1 = 0, P2 = 0, Dr0 = 1, Dr1 = 1, Dr2 = 1, Y0 = 1, Y1 = 1, Y2 = 1;
+    float K0 = 0, K1 = 0, K2 = 0;     // copysign(2e-6 * 2^23, dir): the nudge along each axis
     float dist = 0.0f, tcur = 0.0f;
     int32_t ix = 0, iy = 0, iz = 0;
     uint32_t lvl = 1, nidx = 0;       // next level to read and the child group it lives in
@@ -605,6 +606,9 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
                         Y0 = __uint_as_float(pool[6 * 64 + e]);
                         Y1 = __uint_as_float(pool[7 * 64 + e]);
                         Y2 = __uint_as_float(pool[8 * 64 + e]);
+                        K0 = copysign_bits(0.000002f * 8388608.0f, Dr0);
+                        K1 = copysign_bits(0.000002f * 8388608.0f, Dr1);
+                        K2 = copysign_bits(0.000002f * 8388608.0f, Dr2);
                         dist = __uint_as_float(pool[9 * 64 + e]);
                         out = pool[10 * 64 + e];
                         ix = (int32_t)pool[11 * 64 + e];
@@ -687,15 +691,14 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
             const float t2 = div_by_recip((C2 - P2) + copysign_bits(Hm, Dr2), Dr2, Y2);
             // no NaNs here, so IEEE minNum equals the oracle's (b < a) ? b : a up to the sign of a zero,
             // which no later value depends on
-            const float t12 = __builtin_fminf(t1, t2), t20 = __builtin_fminf(t2, t0), t01 = __builtin_fminf(t0, t1);
-            const bool m0 = t0 <= t12, m1 = t1 <= t20, m2 = t2 <= t01;
-            const float tnew = __builtin_fminf(t01, t2);
+            // (no NaNs, so "t_i <= min(t_j, t_k)" is "t_i equals the minimum of the three")
+            const float tnew = __builtin_fminf(__builtin_fminf(t0, t1), t2);
+            const bool m0 = t0 == tnew, m1 = t1 == tnew, m2 = t2 == tnew;
             // voxel_pos = pos + dir * t - normal * 2e-6, normal = mask * -sign(dir): subtracting -k is adding k
-            constexpr float kNudge = 0.000002f * 8388608.0f;  // exact product
             float G0 = P0 + Dr0 * tnew, G1 = P1 + Dr1 * tnew, G2 = P2 + Dr2 * tnew;
-            G0 = m0 ? G0 + copysign_bits(kNudge, Dr0) : G0;
-            G1 = m1 ? G1 + copysign_bits(kNudge, Dr1) : G1;
-            G2 = m2 ? G2 + copysign_bits(kNudge, Dr2) : G2;
+            G0 = m0 ? G0 + K0 : G0;
+            G1 = m1 ? G1 + K1 : G1;
+            G2 = m2 ? G2 + K2 : G2;
             const bool inb = (__builtin_fmaxf(__builtin_fmaxf(G0, G1), G2) < kScale) &&
                              (__builtin_fminf(__builtin_fminf(G0, G1), G2) >= -kScale);
             const bool stop_here = too_deep || solid;         // finish before stepping
