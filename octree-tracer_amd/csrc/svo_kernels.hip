@@ -493,9 +493,13 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
     // knows leaves that cover a whole level-K cell), else from the lane's ancestor stack.  One LDS read.
     auto restart_at = [&](uint32_t r) {
         const bool top = r <= (uint32_t)(K + 1);
-        const uint32_t cell = ((uint32_t)(ix >> (D - K)) << (2 * K)) | ((uint32_t)(iy >> (D - K)) << K) |
-                              (uint32_t)(iz >> (D - K));
-        const uint32_t e = lds[top ? cell : (uint32_t)TBL + (r - SBASE) * BLOCK + tid];
+        uint32_t addr = (uint32_t)TBL + (r - SBASE) * BLOCK + tid;
+        if (__ballot(top)) {  // wave-uniform: most rounds no lane crosses a level-(K+1) boundary
+            const uint32_t cell = ((uint32_t)(ix >> (D - K)) << (2 * K)) | ((uint32_t)(iy >> (D - K)) << K) |
+                                  (uint32_t)(iz >> (D - K));
+            addr = top ? cell : addr;
+        }
+        const uint32_t e = lds[addr];
         lvl = top ? (e >> 27) : r;
         nidx = e & 0x07FFFFFFu;
     };
@@ -654,11 +658,12 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
             // straight-line body, one exit test: the push also happens on the exiting iteration (it lands in the
             // slot below the leaf, which no restart reads; the stack has one spare row for an exit at level SMAX)
             do {
-                if (a.debug) dbg_iters += 1;  // (per lane; lane 0 of the wave reports its own count)
+                // child = x << 2 | y << 1 | z; byte offset = (nidx + child) << 2.  Three-operand forms the compiler does
+                // not pick by itself (single VALU instructions, no memory, no hazards)
                 uint32_t child = __builtin_amdgcn_ubfe((uint32_t)ix, sh, 1u);
-                child = (child << 1) | __builtin_amdgcn_ubfe((uint32_t)iy, sh, 1u);
-                child = (child << 1) | __builtin_amdgcn_ubfe((uint32_t)iz, sh, 1u);
-                off = (nidx + child) << 2;
+                asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(child) : "v"(child), "v"(__builtin_amdgcn_ubfe((uint32_t)iy, sh, 1u)));
+                asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(child) : "v"(child), "v"(__builtin_amdgcn_ubfe((uint32_t)iz, sh, 1u)));
+                asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(off) : "v"(nidx), "v"(child));
                 w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
                 nidx = w >> 4;
                 lds[sp] = nidx;
@@ -742,7 +747,7 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
         d[2] = (uint32_t)t_end;
         d[3] = n_rounds;
         d[4] = dbg_active;   // sum over rounds of active lanes
-        d[5] = dbg_iters;    // descent iterations of lane 0
+        d[5] = dbg_iters;    // (unused)
         d[6] = dbg_refills;
         d[7] = dbg_gens;
     }
