@@ -144,7 +144,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
             if (sc.order) (void)hipFree(sc.order);
             sc = svo_ctx::Sched{};
             size_t want = n_strips < 4096 ? 4096 : n_strips;
-            HIP_TRY(ctx, hipMalloc((void **)&sc.cost, want + 16));
+            HIP_TRY(ctx, hipMalloc((void **)&sc.cost, want + 32 + svo::kOrderHistWords * sizeof(uint32_t)));
             HIP_TRY(ctx, hipMalloc((void **)&sc.order, (want + 8 * 24 + 8) * sizeof(uint32_t)));
             sc.cap = want;
         }

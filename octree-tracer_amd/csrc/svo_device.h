@@ -71,7 +71,8 @@ hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint3
 hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream);
 int stack_max_depth(bool deep);
 // after a STACK trace: deferred rays, per-strip costs (cost != nullptr) and the next schedule; re-arms the counters
-constexpr uint32_t kMaxScheduledStrips = 147456;  // class bytes of one frame must fit the order kernel's LDS (144 KiB)
+constexpr uint32_t kMaxScheduledStrips = 1u << 20;  // (2^26 items / 64)
+constexpr uint32_t kOrderHistWords = 64 * 16;      // chunk histograms of the schedule builder, stored behind the class bytes
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
                        uint32_t cap, bool build_schedule, hipStream_t stream);
 

@@ -818,26 +818,77 @@ __global__ __launch_bounds__(256) void post_kernel(TraceArgs a, uint32_t *claim_
     }
 }
 
-// Schedule for the next frame.  Strips fall into 16 cost classes (steps / 8).  Classes are walked from the
+// Schedule for the next frames.  Strips fall into 16 cost classes (steps / 8).  Classes are walked from the
 // most expensive down; inside a class the strips stay in screen order and are cut into 8 contiguous
 // segments, one per claim counter (= per XCD, see the kernel).  So every XCD starts its long rays first,
 // gets an equal share of every class, and still walks screen-contiguous runs (node-cache locality).
 // Output: sched[0..7] = entries per list, then 8 lists of `cap` strip numbers each.
-__global__ __launch_bounds__(1024) void strip_order_kernel(const uint8_t *cost_g, uint32_t *sched, uint32_t n_strips,
-                                                           uint32_t cap) {
-    constexpr uint32_t kBins = 16, kThreads = 1024, kLists = 8, kWaves = kThreads / 64;
-    extern __shared__ uint32_t cls_words[];          // the class bytes, staged with coalesced loads
-    __shared__ uint32_t wave_tot[kBins][kWaves];     // strips of a class in each wave's range (then: exclusive prefix)
-    __shared__ uint32_t class_n[kBins], seglen[kBins], seg_magic[kBins];
-    __shared__ uint32_t list_base[kBins][kLists];    // where a class starts inside each list
-    const uint8_t *cls = reinterpret_cast<const uint8_t *>(cls_words);
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    for (uint32_t i = tid; i < (n_strips + 3u) / 4u; i += kThreads)
-        cls_words[i] = reinterpret_cast<const uint32_t *>(cost_g)[i];
+// Two small launches over kOrderBlocks workgroups, each owning a contiguous chunk of strips: class histogram
+// per chunk, then a stable counting sort (ballot + mbcnt ranks inside a wave, prefix over waves and chunks).
+constexpr uint32_t kOrderBlocks = 64, kOrderThreads = 256, kOrderBins = 16, kOrderLists = 8;
+
+__device__ __forceinline__ uint32_t order_chunk(uint32_t n_strips) {
+    return (((n_strips + kOrderBlocks - 1) / kOrderBlocks) + 63u) & ~63u;  // whole 64-strip groups per workgroup
+}
+
+__global__ __launch_bounds__(kOrderThreads) void strip_hist_kernel(const uint8_t *cls, uint32_t n_strips, uint32_t *hist) {
+    __shared__ uint32_t tally[kOrderBins];
+    if (threadIdx.x < kOrderBins) tally[threadIdx.x] = 0;
     __syncthreads();
-    // each wave owns a contiguous range of strips and walks it 64 at a time; lanes 0..15 keep the class tallies
-    const uint32_t per_wave = (((n_strips + kWaves - 1) / kWaves) + 63u) & ~63u;
-    const uint32_t lo = min(wv * per_wave, n_strips), hi = min(lo + per_wave, n_strips);
+    const uint32_t chunk = order_chunk(n_strips);
+    const uint32_t lo = min(blockIdx.x * chunk, n_strips), hi = min(lo + chunk, n_strips);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = lo + (threadIdx.x & ~63u); base < hi; base += kOrderThreads) {
+        const uint32_t s = base + lane;
+        const uint32_t c = s < hi ? cls[s] : 0xFFu;
+        uint64_t todo = __ballot(c != 0xFFu);
+        while (todo) {  // one LDS atomic per (wave, class present) instead of one per strip
+            const uint32_t b = __builtin_amdgcn_readlane(c, __ffsll((unsigned long long)todo) - 1);
+            const uint64_t m = __ballot(c == b);
+            if (lane == 0) atomicAdd(&tally[b], (uint32_t)__popcll(m));
+            todo &= ~m;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kOrderBins) hist[blockIdx.x * kOrderBins + threadIdx.x] = tally[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kOrderThreads) void strip_order_kernel(const uint8_t *cls, const uint32_t *hist, uint32_t *sched,
+                                                                    uint32_t n_strips, uint32_t cap) {
+    constexpr uint32_t kWaves = kOrderThreads / 64;
+    __shared__ uint32_t class_n[kOrderBins], before[kOrderBins], seglen[kOrderBins], seg_magic[kOrderBins];
+    __shared__ uint32_t list_base[kOrderBins][kOrderLists];
+    __shared__ uint32_t wave_tot[kOrderBins][kWaves];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid < kOrderBins) {  // class totals and the count in the chunks before this one
+        uint32_t total = 0, prior = 0;
+        for (uint32_t b = 0; b < kOrderBlocks; b++) {
+            const uint32_t c = hist[b * kOrderBins + tid];
+            prior += b < blockIdx.x ? c : 0u;
+            total += c;
+        }
+        class_n[tid] = total;
+        before[tid] = prior;
+        const uint32_t sl = max((total + kOrderLists - 1) / kOrderLists, 1u);
+        seglen[tid] = sl;
+        seg_magic[tid] = sl <= 1u ? 0u : (uint32_t)(0x100000000ull / sl) + 1u;
+    }
+    __syncthreads();
+    if (tid < kOrderLists) {
+        uint32_t acc = 0;
+        for (int b = kOrderBins - 1; b >= 0; b--) {  // expensive classes first
+            list_base[b][tid] = acc;
+            const uint32_t n = class_n[b], sl = seglen[b];
+            const uint32_t begin = min(tid * sl, n), endp = min(begin + sl, n);
+            acc += endp - begin;
+        }
+        if (blockIdx.x == 0) sched[tid] = acc;
+    }
+    // each wave owns a contiguous run of 64-strip groups of the chunk; lanes 0..15 keep the class tallies
+    const uint32_t chunk = order_chunk(n_strips);
+    const uint32_t clo = min(blockIdx.x * chunk, n_strips), chi = min(clo + chunk, n_strips);
+    const uint32_t per_wave = (((chunk / 64u) + kWaves - 1) / kWaves) * 64u;
+    const uint32_t lo = min(clo + wv * per_wave, chi), hi = min(lo + per_wave, chi);
     uint32_t tally = 0;
     for (uint32_t base = lo; base < hi; base += 64u) {
         const uint32_t s = base + lane;
@@ -850,29 +901,13 @@ __global__ __launch_bounds__(1024) void strip_order_kernel(const uint8_t *cost_g
             todo &= ~m;
         }
     }
-    if (lane < kBins) wave_tot[lane][wv] = tally;
+    if (lane < kOrderBins) wave_tot[lane][wv] = tally;
     __syncthreads();
-    if (tid < kBins) {
-        uint32_t acc = 0;
-        for (uint32_t w = 0; w < kWaves; w++) { uint32_t c = wave_tot[tid][w]; wave_tot[tid][w] = acc; acc += c; }
-        class_n[tid] = acc;
-        const uint32_t sl = max((acc + kLists - 1) / kLists, 1u);
-        seglen[tid] = sl;
-        seg_magic[tid] = sl <= 1u ? 0u : (uint32_t)(0x100000000ull / sl) + 1u;
+    uint32_t run = 0;  // rank (inside its class) of the wave's next strip of class `lane`
+    if (lane < kOrderBins) {
+        run = before[lane];
+        for (uint32_t w = 0; w < wv; w++) run += wave_tot[lane][w];
     }
-    __syncthreads();
-    if (tid < kLists) {
-        uint32_t acc = 0;
-        for (int b = kBins - 1; b >= 0; b--) {  // expensive classes first
-            list_base[b][tid] = acc;
-            const uint32_t n = class_n[b], sl = seglen[b];
-            const uint32_t begin = min(tid * sl, n), endp = min(begin + sl, n);
-            acc += endp - begin;
-        }
-        sched[tid] = acc;
-    }
-    __syncthreads();
-    uint32_t run = lane < kBins ? wave_tot[lane][wv] : 0u;  // rank of the wave's next strip of class `lane`
     for (uint32_t base = lo; base < hi; base += 64u) {
         const uint32_t s = base + lane;
         const uint32_t c = s < hi ? cls[s] : 0xFFu;
@@ -890,7 +925,7 @@ __global__ __launch_bounds__(1024) void strip_order_kernel(const uint8_t *cost_g
         if (c != 0xFFu) {
             const uint32_t sl = seglen[c];
             const uint32_t list = fast_div(rank, sl, seg_magic[c]), within = rank - list * sl;
-            sched[kLists + list * cap + list_base[c][list] + within] = s;
+            sched[kOrderLists + list * cap + list_base[c][list] + within] = s;
         }
     }
 }
@@ -1078,9 +1113,13 @@ hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cos
     if (blocks < 16u) blocks = 16u;
     hipLaunchKernelGGL(post_kernel, dim3(blocks), dim3(256), 0, stream, args, li.counters, (const uint32_t *)li.defer,
                        li.next_defer_count, cost, n_strips);
-    if (cost && build_schedule)
-        hipLaunchKernelGGL(strip_order_kernel, dim3(1), dim3(1024), (size_t)((n_strips + 3u) / 4u) * 4u, stream,
-                           (const uint8_t *)cost, sched, n_strips, cap);
+    if (cost && build_schedule) {
+        // the chunk histograms live behind the class bytes (the ABI allocates kOrderHistWords extra words)
+        uint32_t *hist = reinterpret_cast<uint32_t *>(cost + ((n_strips + 15u) & ~15u));
+        hipLaunchKernelGGL(strip_hist_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, (const uint8_t *)cost, n_strips, hist);
+        hipLaunchKernelGGL(strip_order_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, (const uint8_t *)cost,
+                           (const uint32_t *)hist, sched, n_strips, cap);
+    }
     return hipGetLastError();
 }
 

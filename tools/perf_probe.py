@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--prio", default="0")
     ap.add_argument("--schedule", default="8")
     ap.add_argument("--block", default="3")
+    ap.add_argument("--motion", type=float, default=0.0, help="degrees of yaw added to the camera every frame")
     a = ap.parse_args()
     pkg = entry.load_package()
     import torch
@@ -68,6 +69,12 @@ def main():
         gpu.set_option(pkg.gpu.OPT_BLOCK_SHAPE, blockw)
         ms = []
         for i in range(a.reps + 2):
+            if a.motion:
+                import math
+                ang = math.radians(a.motion) * (i + 1)
+                lx, ly, lz = look
+                rl = (lx * math.cos(ang) + lz * math.sin(ang), ly, -lx * math.sin(ang) + lz * math.cos(ang))
+                render.update(pkg.Settings(), pkg.Character(cam, rl))
             render.render(hits=hits)
             t = gpu.last_render_ms()
             if i >= 2:
@@ -77,7 +84,7 @@ def main():
         sig = int(np.bitwise_xor.reduce(h.reshape(-1)))
         if ref is None:
             ref = h.copy()
-        same = bool(np.array_equal(ref, h))
+        same = bool(np.array_equal(ref, h)) if not a.motion else None
         med = float(np.median(ms))
         print(json.dumps({"variant": variant, "refill": refill, "strip": strip, "dynamic": dyn, "grid": grid, "prio": prio, "schedule": sched, "block": blockw,
                           "ms_med": round(med, 4), "ms_min": round(min(ms), 4), "mrays_s": round(n / med / 1e3, 1),
