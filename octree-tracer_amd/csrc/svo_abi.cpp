@@ -52,7 +52,7 @@ struct svo_ctx {
     };
     Sched sched[2];
     bool schedule = true;
-    uint32_t sched_period = 8;  // frames between schedule rebuilds
+    uint32_t sched_period = 2;  // frames between schedule rebuilds (tools/perf_probe.py --motion: 2 keeps the gain under camera motion)
     int frame_parity = 0;
     // shading pass scratch (svo_render with rgba_out)
     void *shade_hits = nullptr, *shade_aux = nullptr, *shade_rays = nullptr, *shade_shadow = nullptr;
