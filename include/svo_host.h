@@ -10,6 +10,11 @@
  *                         (world.rs:234-336)
  *   svo_octree_*          Octree (octree.rs:43-162): new :51-66, subdivide :72-93, unsubdivide
  *                         :95-110, find_voxel :113-141, expanded :143-148, pos_offset :154-161
+ *   svo_world_*           World (world.rs:5-9): chunk table with block references; find_voxel :201-232,
+ *                         generate_mip_tree :234-336, save_chunk / load_chunk / load_world :159-198;
+ *                         svo_cpu_octree_bin / _from_bin: CpuOctree::bin / from_bin (cpu_octree.rs:262-272)
+ *   svo_adaptive_*        process_subdivision / process_unsubdivision (adaptive.rs:6-126), the list
+ *                         processing after the read-back that svo_scan_read performs
  *   svo_camera_matrices   Render::update (render.rs:191-206) + create_proj_matrix (main.rs:139-162)
  *   svo_gen_*             no counterpart: the reference's generator (procedual.wgsl) is racy and
  *                         nondeterministic; these are deterministic CPU scene builders for the
@@ -80,6 +85,42 @@ void svo_octree_pos_offset(uint32_t child_index, uint32_t depth, float out[3]);
 size_t svo_octree_holes(const svo_octree *o);
 void svo_octree_set_node(svo_octree *o, size_t index, uint32_t word);   /* octree.nodes[i] = word (adaptive.rs:117) */
 void svo_octree_position(const svo_octree *o, size_t index, float out[3]); /* octree.positions[i] */
+
+/* ---- World: chunks, block instancing, chunk dumps ---- */
+typedef struct svo_world svo_world;
+/* World::new(path) WITHOUT the eight block .vox loads of world.rs:19-58: the caller inserts block chunks
+ * 1..8 (svo_cpu_octree_load_file + svo_world_insert + svo_world_generate_mip_tree), see INTEGRATION.md. */
+svo_world *svo_world_new(const char *path);
+void svo_world_free(svo_world *w);
+const char *svo_world_last_error(const svo_world *w);
+/* chunks.insert(id, chunk): the world takes ownership of the chunk (an existing chunk of that id is freed) */
+int svo_world_insert(svo_world *w, uint32_t id, svo_cpu_octree *chunk);
+int svo_world_remove(svo_world *w, uint32_t id);                      /* 0 removed, 1 not present */
+svo_cpu_octree *svo_world_chunk(const svo_world *w, uint32_t id);     /* borrowed; NULL if absent */
+size_t svo_world_chunk_ids(const svo_world *w, uint32_t *ids, size_t cap);
+/* (chunk, index, depth, pos); -1 where the reference would panic on a chunk that is not loaded */
+int svo_world_find_voxel(const svo_world *w, const float pos[3], int64_t max_depth, uint32_t *chunk,
+                         uint64_t *index, uint32_t *depth, float node_pos[3]);
+/* block leaves take the referenced chunk's top_mip, interior nodes the mean of their children */
+int svo_world_generate_mip_tree(svo_world *w, uint32_t id, uint8_t top_mip[3]);
+/* <path>/<id>.bin: 8 bytes per node (LE u32 pointer, r, g, b, one pad byte) */
+int svo_world_save_chunk(svo_world *w, uint32_t id);
+int svo_world_load_chunk(svo_world *w, uint32_t id);                  /* synchronous (reference: tokio task) */
+svo_world *svo_world_load(const char *path, char *err, size_t errlen); /* load_world: reads <path>/0.bin */
+size_t svo_cpu_octree_bin(const svo_cpu_octree *t, uint8_t *out, size_t cap);
+svo_cpu_octree *svo_cpu_octree_from_bin(const uint8_t *data, size_t len, char *err, size_t errlen);
+
+/* ---- streaming loop, CPU half (adaptive.rs) ---- */
+/* lists as svo_scan_read returns them (node indices). Returns nodes (un)subdivided, -1 on error
+ * (svo_world_last_error).  A listed leaf whose block/chunk is not loaded triggers a load and is skipped
+ * this time, as in the reference (*chunks_loaded counts them). */
+int64_t svo_adaptive_subdivide(svo_world *w, svo_octree *o, const uint32_t *list, size_t n, uint64_t *chunks_loaded);
+int64_t svo_adaptive_unsubdivide(svo_world *w, svo_octree *o, const uint32_t *list, size_t n);
+/* Fixed point of the subdivision loop without a device: every leaf with world children is subdivided, pass by
+ * pass in index order, while depth < max_depth and (lod_c <= 0 or 2^depth * distance(cam, cube) < lod_c) and
+ * the array stays <= max_words.  Returns the number of subdivisions. */
+uint64_t svo_world_expand(svo_world *w, svo_octree *o, uint32_t max_depth, const float cam[3], float lod_c,
+                          uint64_t max_words);
 
 /* ---- camera ---- */
 void svo_camera_matrices(const float pos[3], const float look[3], float fov_deg, float width, float height,

@@ -52,6 +52,10 @@ HOST_SYMBOLS = [
     "svo_octree_new", "svo_octree_from_words", "svo_octree_free", "svo_octree_len", "svo_octree_raw_data",
     "svo_octree_get_node", "svo_octree_subdivide", "svo_octree_unsubdivide", "svo_octree_find_voxel",
     "svo_octree_expanded", "svo_octree_pos_offset", "svo_octree_holes", "svo_octree_set_node", "svo_octree_position", "svo_camera_matrices",
+    "svo_world_new", "svo_world_free", "svo_world_last_error", "svo_world_insert", "svo_world_remove",
+    "svo_world_chunk", "svo_world_chunk_ids", "svo_world_find_voxel", "svo_world_generate_mip_tree",
+    "svo_world_save_chunk", "svo_world_load_chunk", "svo_world_load", "svo_cpu_octree_bin", "svo_cpu_octree_from_bin",
+    "svo_adaptive_subdivide", "svo_adaptive_unsubdivide", "svo_world_expand",
     "svo_gen_terrain", "svo_gen_terrain_height", "svo_gen_fractal", "svo_gen_random", "svo_nodes_max_depth",
 ]
 
@@ -130,6 +134,23 @@ def lib():
     sig("svo_octree_holes", sz, vp)
     sig("svo_octree_set_node", None, vp, sz, u32)
     sig("svo_octree_position", None, vp, sz, fp)
+    sig("svo_world_new", vp, cp)
+    sig("svo_world_free", None, vp)
+    sig("svo_world_last_error", cp, vp)
+    sig("svo_world_insert", C.c_int, vp, u32, vp)
+    sig("svo_world_remove", C.c_int, vp, u32)
+    sig("svo_world_chunk", vp, vp, u32)
+    sig("svo_world_chunk_ids", sz, vp, vp, sz)
+    sig("svo_world_find_voxel", C.c_int, vp, fp, i64, C.POINTER(u32), C.POINTER(u64), C.POINTER(u32), fp)
+    sig("svo_world_generate_mip_tree", C.c_int, vp, u32, C.POINTER(C.c_uint8))
+    sig("svo_world_save_chunk", C.c_int, vp, u32)
+    sig("svo_world_load_chunk", C.c_int, vp, u32)
+    sig("svo_world_load", vp, cp, cp, sz)
+    sig("svo_cpu_octree_bin", sz, vp, vp, sz)
+    sig("svo_cpu_octree_from_bin", vp, cp, sz, cp, sz)
+    sig("svo_adaptive_subdivide", i64, vp, vp, vp, sz, C.POINTER(u64))
+    sig("svo_adaptive_unsubdivide", i64, vp, vp, vp, sz)
+    sig("svo_world_expand", u64, vp, vp, u32, fp, f32, u64)
     sig("svo_camera_matrices", None, fp, fp, f32, f32, f32, fp, fp)
     sig("svo_gen_terrain", u64, C.POINTER(TerrainParams), vp, u64)
     sig("svo_gen_terrain_height", C.c_int32, u32, u32, u32, u32)

@@ -10,8 +10,9 @@ CHUNK_OFFSET = 2147483648  # cpu_octree.rs:3
 
 
 class CpuOctree:
-    def __init__(self, mask=0, _handle=None):
+    def __init__(self, mask=0, _handle=None, _owned=True):
         self._h = _handle if _handle else lib().svo_cpu_octree_new(mask)
+        self._owned = _owned  # False once a World holds the chunk (world.py)
 
     @classmethod
     def new(cls, mask=0):
@@ -49,9 +50,9 @@ class CpuOctree:
                                                           palette.ctypes.data, err, 256), err)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and self._owned:
             lib().svo_cpu_octree_free(self._h)
-            self._h = None
+        self._h = None
 
     def __len__(self):
         return lib().svo_cpu_octree_len(self._h)
@@ -93,6 +94,19 @@ class CpuOctree:
         top = (C.c_uint8 * 3)()
         lib().svo_cpu_octree_generate_mips(self._h, top)
         return Voxel(*top)
+
+    def bin(self):
+        """CpuOctree::bin (cpu_octree.rs:262-264): the <id>.bin image, 8 bytes per node."""
+        n = lib().svo_cpu_octree_bin(self._h, None, 0)
+        buf = np.empty(n, dtype=np.uint8)
+        lib().svo_cpu_octree_bin(self._h, buf.ctypes.data, n)
+        return buf.tobytes()
+
+    @classmethod
+    def from_bin(cls, data: bytes):
+        """CpuOctree::from_bin (cpu_octree.rs:266-272)"""
+        err = C.create_string_buffer(256)
+        return cls._wrap(lib().svo_cpu_octree_from_bin(data, len(data), err, 256), err)
 
     def to_rsvo(self):
         n = lib().svo_rsvo_write(self._h, None, 0)

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -498,6 +499,338 @@ int svo_octree_expanded(const svo_octree *o, size_t size, uint32_t *out) {
 void svo_octree_pos_offset(uint32_t child_index, uint32_t depth, float out[3]) {
     const Vec3 v = pos_offset(child_index, depth);
     out[0] = v.x; out[1] = v.y; out[2] = v.z;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// World: chunk table with block instancing (world.rs), chunk dumps, and the CPU half of the
+// streaming loop (adaptive.rs)
+// ------------------------------------------------------------------------------------------
+struct svo_world {
+    std::string path;
+    std::map<uint32_t, svo_cpu_octree *> chunks;
+    mutable std::string error;
+
+    ~svo_world() {
+        for (auto &kv : chunks) delete kv.second;
+    }
+    svo_cpu_octree *get(uint32_t id) const {
+        auto it = chunks.find(id);
+        return it == chunks.end() ? nullptr : it->second;
+    }
+};
+
+namespace {
+
+struct WorldLocated {
+    uint32_t chunk;
+    size_t index;
+    uint32_t depth;
+    Vec3 pos;
+    bool ok;
+};
+
+// World::find_voxel (world.rs:201-232): the `>=` walk, hopping into the referenced chunk's root group at a
+// block leaf.  The reference unwraps a missing chunk (panic); here ok = false.
+WorldLocated world_locate(const svo_world &w, Vec3 p, int64_t max_depth) {
+    uint32_t chunk = 0;
+    size_t base = 0;
+    Vec3 c;
+    const svo_cpu_octree *cur = w.get(0);
+    for (uint32_t depth = 1;; ++depth) {
+        if (!cur) return {chunk, 0, depth, c, false};
+        const uint32_t child = (p.x >= c.x ? 4u : 0u) | (p.y >= c.y ? 2u : 0u) | (p.z >= c.z ? 1u : 0u);
+        const Vec3 o = pos_offset(child, depth);
+        c.x += o.x; c.y += o.y; c.z += o.z;
+        if (base + child >= cur->nodes.size()) return {chunk, base + child, depth, c, false};
+        const uint32_t ptr = cur->nodes[base + child].pointer;
+        if (ptr == kChunkOffset || (max_depth >= 0 && int64_t(depth) == max_depth)) return {chunk, base + child, depth, c, true};
+        if (ptr > kChunkOffset) {
+            chunk = ptr - kChunkOffset;
+            cur = w.get(chunk);
+            base = 0;
+        } else {
+            base = ptr;
+        }
+        if (depth >= 64) return {chunk, base, depth, c, false};  // cyclic chunk references
+    }
+}
+
+// <id>.bin (world.rs:176-184, cpu_octree.rs:262-272): the reference dumps its Vec<Node> as raw memory.  Node is
+// {pointer: u32, value: Voxel{r, g, b: u8}}: 8 bytes with rustc's layout (pointer at 0, r g b at 4..6, one
+// padding byte); little-endian.  The layout is what rustc produces in practice, not a language guarantee.
+constexpr size_t kBinNodeBytes = 8;
+
+std::string chunk_file(const svo_world &w, uint32_t id) { return w.path + "/" + std::to_string(id) + ".bin"; }
+
+svo_cpu_octree *tree_from_bin(const uint8_t *d, size_t len) {
+    auto *t = new svo_cpu_octree();
+    t->top_mip = Rgb{};  // from_bin, cpu_octree.rs:270
+    t->nodes.resize(len / kBinNodeBytes);
+    for (size_t i = 0; i < t->nodes.size(); i++) {
+        const uint8_t *n = d + i * kBinNodeBytes;
+        t->nodes[i] = {le32(n), Rgb{n[4], n[5], n[6]}};
+    }
+    return t;
+}
+
+bool read_file(const std::string &p, std::vector<uint8_t> &buf) {
+    FILE *f = fopen(p.c_str(), "rb");
+    if (!f) return false;
+    uint8_t tmp[65536];
+    size_t got;
+    while ((got = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+    fclose(f);
+    return true;
+}
+
+int world_fail(svo_world *w, const std::string &msg) {
+    w->error = msg;
+    return -1;
+}
+
+// what process_subdivision does for one listed node (adaptive.rs:29-61); `loaded` counts chunk loads
+// returns 1 subdivided, 0 skipped, -1 error
+int subdivide_one(svo_world *w, svo_octree *o, size_t node_index, uint64_t *loaded) {
+    if (node_index >= o->nodes.size()) return world_fail(w, "node index past the octree");
+    if ((o->nodes[node_index] >> 4) < kVoxelOffset) return 0;  // "Doubleup!" :32-35
+    const Vec3 pos = o->positions[node_index];
+    uint32_t voxel_depth = 0;
+    {
+        const float p[3] = {pos.x, pos.y, pos.z};
+        svo_octree_find_voxel(o, p, -1, nullptr, &voxel_depth, nullptr);
+    }
+    const WorldLocated l = world_locate(*w, pos, voxel_depth);
+    if (!l.ok) return world_fail(w, "world walk left the loaded chunks (chunk " + std::to_string(l.chunk) + ")");
+    const svo_cpu_octree *chunk = w->get(l.chunk);
+    const uint32_t ptr = chunk->nodes[l.index].pointer;
+    uint8_t mask[24];
+    if (ptr < kChunkOffset) {  // :42-48
+        if (size_t(ptr) + 8 > chunk->nodes.size()) return world_fail(w, "child pointer past the chunk");
+        svo_cpu_octree_get_node_mask(chunk, ptr, mask);
+    } else if (ptr > kChunkOffset) {  // :49-58
+        const uint32_t id = ptr - kChunkOffset;
+        const svo_cpu_octree *block = w->get(id);
+        if (!block) {
+            // the reference starts an asynchronous load and retries when the node is listed again
+            if (svo_world_load_chunk(w, id) == 0 && loaded) ++*loaded;
+            return 0;
+        }
+        if (block->nodes.size() < 8) return 0;  // a chunk whose nodes were dropped to save memory (world.rs:134)
+        svo_cpu_octree_get_node_mask(block, 0, mask);
+    } else {
+        return 0;
+    }
+    return svo_octree_subdivide(o, node_index, mask, voxel_depth + 1) == 0 ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+svo_world *svo_world_new(const char *path) {
+    auto *w = new svo_world();
+    w->path = path ? path : "";
+    return w;
+}
+void svo_world_free(svo_world *w) { delete w; }
+const char *svo_world_last_error(const svo_world *w) { return w->error.c_str(); }
+
+int svo_world_insert(svo_world *w, uint32_t id, svo_cpu_octree *chunk) {
+    if (!chunk) return world_fail(w, "null chunk");
+    auto it = w->chunks.find(id);
+    if (it != w->chunks.end()) {
+        if (it->second != chunk) delete it->second;
+        it->second = chunk;
+    } else {
+        w->chunks[id] = chunk;
+    }
+    return 0;
+}
+int svo_world_remove(svo_world *w, uint32_t id) {
+    auto it = w->chunks.find(id);
+    if (it == w->chunks.end()) return 1;
+    delete it->second;
+    w->chunks.erase(it);
+    return 0;
+}
+svo_cpu_octree *svo_world_chunk(const svo_world *w, uint32_t id) { return w->get(id); }
+size_t svo_world_chunk_ids(const svo_world *w, uint32_t *ids, size_t cap) {
+    size_t n = 0;
+    for (auto &kv : w->chunks) {
+        if (ids && n < cap) ids[n] = kv.first;
+        n++;
+    }
+    return n;
+}
+
+int svo_world_find_voxel(const svo_world *w, const float pos[3], int64_t max_depth, uint32_t *chunk, uint64_t *index,
+                         uint32_t *depth, float node_pos[3]) {
+    const WorldLocated l = world_locate(*w, {pos[0], pos[1], pos[2]}, max_depth);
+    if (chunk) *chunk = l.chunk;
+    if (index) *index = l.index;
+    if (depth) *depth = l.depth;
+    if (node_pos) { node_pos[0] = l.pos.x; node_pos[1] = l.pos.y; node_pos[2] = l.pos.z; }
+    if (!l.ok) w->error = "world walk left the loaded chunks (chunk " + std::to_string(l.chunk) + ")";
+    return l.ok ? 0 : -1;
+}
+
+// World::generate_mip_tree (world.rs:234-336): block leaves take the referenced chunk's top_mip first
+// (:249-253, :273-279), then interior nodes are averaged bottom-up and the root average becomes top_mip.
+int svo_world_generate_mip_tree(svo_world *w, uint32_t id, uint8_t top_mip[3]) {
+    svo_cpu_octree *t = w->get(id);
+    if (!t) return world_fail(w, "no chunk " + std::to_string(id));
+    if (t->nodes.size() < 8) return world_fail(w, "chunk " + std::to_string(id) + " has no nodes");
+    for (auto &n : t->nodes) {
+        // every node of the array is reachable in a tree built by the loaders, so one linear pass equals
+        // the reference's walk over reachable block leaves
+        if (n.pointer > kChunkOffset) {
+            const svo_cpu_octree *b = w->get(n.pointer - kChunkOffset);
+            if (!b) return world_fail(w, "block " + std::to_string(n.pointer - kChunkOffset) + " is not loaded");
+            n.value = b->top_mip;
+        }
+    }
+    svo_cpu_octree_generate_mips(t, top_mip);
+    return 0;
+}
+
+size_t svo_cpu_octree_bin(const svo_cpu_octree *t, uint8_t *out, size_t cap) {
+    const size_t total = t->nodes.size() * kBinNodeBytes;
+    if (!out || cap < total) return total;
+    for (size_t i = 0; i < t->nodes.size(); i++) {
+        uint8_t *n = out + i * kBinNodeBytes;
+        put32(n, t->nodes[i].pointer);
+        n[4] = t->nodes[i].value.r; n[5] = t->nodes[i].value.g; n[6] = t->nodes[i].value.b; n[7] = 0;
+    }
+    return total;
+}
+
+svo_cpu_octree *svo_cpu_octree_from_bin(const uint8_t *data, size_t len, char *err, size_t errlen) {
+    if (len == 0 || len % kBinNodeBytes || (len / kBinNodeBytes) % 8) {
+        put_err(err, errlen, "chunk dump is not a whole number of 8-node groups");
+        return nullptr;
+    }
+    return tree_from_bin(data, len);
+}
+
+int svo_world_save_chunk(svo_world *w, uint32_t id) {
+    const svo_cpu_octree *t = w->get(id);
+    if (!t) return world_fail(w, "no chunk " + std::to_string(id));
+    std::vector<uint8_t> buf(svo_cpu_octree_bin(t, nullptr, 0));
+    svo_cpu_octree_bin(t, buf.data(), buf.size());
+    FILE *f = fopen(chunk_file(*w, id).c_str(), "wb");
+    if (!f) return world_fail(w, "cannot create " + chunk_file(*w, id));
+    const bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    fclose(f);
+    return ok ? 0 : world_fail(w, "short write to " + chunk_file(*w, id));
+}
+
+// World::load_chunk (world.rs:186-198) without the tokio task: the chunk is there when the call returns.
+int svo_world_load_chunk(svo_world *w, uint32_t id) {
+    std::vector<uint8_t> buf;
+    if (!read_file(chunk_file(*w, id), buf)) return world_fail(w, "cannot read " + chunk_file(*w, id));
+    char why[128] = "";
+    svo_cpu_octree *t = svo_cpu_octree_from_bin(buf.data(), buf.size(), why, sizeof why);
+    if (!t) return world_fail(w, chunk_file(*w, id) + ": " + why);
+    return svo_world_insert(w, id, t);
+}
+
+// World::load_world (world.rs:159-174): a world directory is opened by reading its root chunk 0.bin.
+svo_world *svo_world_load(const char *path, char *err, size_t errlen) {
+    svo_world *w = svo_world_new(path);
+    if (svo_world_load_chunk(w, 0) != 0) {
+        put_err(err, errlen, w->error);
+        delete w;
+        return nullptr;
+    }
+    return w;
+}
+
+int64_t svo_adaptive_subdivide(svo_world *w, svo_octree *o, const uint32_t *list, size_t n, uint64_t *chunks_loaded) {
+    int64_t done = 0;
+    if (chunks_loaded) *chunks_loaded = 0;
+    for (size_t i = 0; i < n; i++) {
+        const int r = subdivide_one(w, o, list[i], chunks_loaded);
+        if (r < 0) return -1;
+        done += r;
+    }
+    return done;
+}
+
+// process_unsubdivision (adaptive.rs:93-121)
+int64_t svo_adaptive_unsubdivide(svo_world *w, svo_octree *o, const uint32_t *list, size_t n) {
+    int64_t done = 0;
+    for (size_t i = 0; i < n; i++) {
+        const size_t node_index = list[i];
+        if (node_index >= o->nodes.size()) return world_fail(w, "node index past the octree");
+        const int r = svo_octree_unsubdivide(o, node_index);  // :95
+        if (r < 0) return world_fail(w, "Tried to unsubdivide a node without position!");
+        const Vec3 pos = o->positions[node_index];
+        const float p[3] = {pos.x, pos.y, pos.z};
+        uint32_t voxel_depth = 0;
+        svo_octree_find_voxel(o, p, -1, nullptr, &voxel_depth, nullptr);
+        const WorldLocated l = world_locate(*w, pos, voxel_depth);
+        if (!l.ok) return world_fail(w, "world walk left the loaded chunks (chunk " + std::to_string(l.chunk) + ")");
+        const auto node = w->get(l.chunk)->nodes[l.index];
+        if (node.pointer > kChunkOffset) {  // :104-110: streamed chunks are dropped, blocks stay
+            const uint32_t id = node.pointer - kChunkOffset;
+            if (id >= kChunkOffset / 2) svo_world_remove(w, id);
+        }
+        o->nodes[node_index] = node.value.gpu_word();  // :117
+        done += r == 0;
+    }
+    return done;
+}
+
+// The streaming loop's fixed point for a given view rule, without a device: pass after pass, every leaf whose
+// world node has children is subdivided in index order (= process_subdivision fed all such leaves, sorted), so
+// the array comes out breadth-first.  A leaf at depth d is refined while d < max_depth and, if lod_c > 0,
+// 2^d < lod_c / distance(cam, its cube) -- the rule of the terrain generator below.  Stops at max_words.
+uint64_t svo_world_expand(svo_world *w, svo_octree *o, uint32_t max_depth, const float cam[3], float lod_c,
+                          uint64_t max_words) {
+    struct Leaf { size_t index; uint32_t depth; };
+    std::vector<Leaf> frontier, next;
+    for (size_t i = 0; i < o->nodes.size(); i++) {
+        if ((o->nodes[i] >> 4) < kVoxelOffset) continue;
+        const Vec3 pos = o->positions[i];
+        const float p[3] = {pos.x, pos.y, pos.z};
+        uint32_t d = 0;
+        svo_octree_find_voxel(o, p, -1, nullptr, &d, nullptr);
+        frontier.push_back({i, d});
+    }
+    uint64_t done = 0;
+    while (!frontier.empty()) {
+        next.clear();
+        for (const Leaf &lf : frontier) {
+            if (lf.depth >= max_depth) continue;
+            if (o->nodes.size() + 8 > max_words && o->hole_stack.empty()) return done;
+            if (lod_c > 0.0f && cam) {
+                const Vec3 c = o->positions[lf.index];
+                const float h = 1.0f / float(1u << lf.depth);  // half edge of a depth-d cube
+                float d2 = 0.0f;
+                const float cc[3] = {c.x, c.y, c.z};
+                for (int k = 0; k < 3; k++) {
+                    const float lo = cc[k] - h, hi = cc[k] + h;
+                    const float d = cam[k] < lo ? lo - cam[k] : (cam[k] > hi ? cam[k] - hi : 0.0f);
+                    d2 += d * d;
+                }
+                const float r = std::sqrt(d2);
+                if (!(float(1u << lf.depth) * r < lod_c)) continue;
+            }
+            const size_t before_holes = o->hole_stack.size();
+            const size_t before = o->nodes.size();
+            const int r = subdivide_one(w, o, lf.index, nullptr);
+            if (r < 0) return done;
+            if (r == 1) {
+                const size_t first = before_holes ? size_t(o->nodes[lf.index] >> 4) : before;
+                for (size_t k = 0; k < 8; k++) next.push_back({first + k, lf.depth + 1});
+                done++;
+            }
+        }
+        frontier.swap(next);
+    }
+    return done;
 }
 
 // ------------------------------------------------------------------------------------------

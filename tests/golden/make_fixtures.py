@@ -30,6 +30,14 @@ def main():
                             palette=pal, n_words=np.array([words.size], dtype=np.uint64),
                             words_crc=np.array([int(np.bitwise_xor.reduce(words * np.arange(1, words.size + 1, dtype=np.uint32)))],
                                                dtype=np.uint64))
+    # the eight 16^3 block models the reference's World instances (world.rs:19-58), decoded like the others
+    blocks = {}
+    for name in ("stone", "dirt", "grass", "wood", "leaf", "slate", "crystal", "glass"):
+        size, xyzi, pal = O.vox_parse(open(os.path.join(os.path.dirname(REF), "blocks", name + ".vox"), "rb").read())
+        assert size == (16, 16, 16)
+        blocks[name + "_xyzi"] = xyzi
+        blocks[name + "_palette"] = pal
+    np.savez_compressed(os.path.join(HERE, "blocks_vox.npz"), **blocks)
     # config 1: small.vox, 256x256, default camera (main.rs:131-132), fov 90, static tree
     data = open(os.path.join(REF, "small.vox"), "rb").read()
     words = O.Tree.from_vox(data).to_octree()

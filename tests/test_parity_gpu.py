@@ -346,7 +346,7 @@ def test_adaptive_streaming_loop(pkg, gpu, O, monu9_words):
     assert (words & 15 == 0).all()  # host words carry counter 0 (octree.rs:28-30,164-166)
     # a leaf of the streamed tree shows the world's colour (mip or voxel) at that position and depth
     rng = np.random.default_rng(1)
-    ptrs, rgb = world.chunk.raw()
+    ptrs, rgb = world.chunk(0).raw()
     for p in rng.uniform(-0.9, 0.9, (50, 3)).astype(np.float32):
         idx, depth, _ = octree.find_voxel(p.tolist())
         _, cidx, _, _ = world.find_voxel(p.tolist(), depth)
