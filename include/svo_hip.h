@@ -15,6 +15,9 @@
  *                                 per pixel (render.rs:217-284, shader.wgsl:250-305)
  *   svo_trace_rays                octree_ray on caller-supplied rays (shader.wgsl:191-248; the
  *                                 shadow ray of shader.wgsl:276 is such a ray)
+ *   svo_render_secondary /        no reference entry point: benchmark config 5 (BASELINE.json configs[4]) --
+ *   svo_render_tiles_secondary    primary rays plus up to 4 secondary rays per hit pixel; ray 0 is fs_main's
+ *                                 shadow ray (shader.wgsl:275-280), the others reuse its origin
  *   svo_scan_dispatch             Compute::update: dispatch(ceil(n/16/256), 256, 1) of
  *                                 compute.wgsl main (compute.rs:99-127, compute.wgsl:26-47)
  *   svo_scan_read                 map_async + device.poll(Wait) + counter reset
@@ -132,6 +135,20 @@ int svo_render_host(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t x0, 
 int svo_render_tiles(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t tile_w,
                      uint32_t tile_h, uint32_t first_tile, uint32_t tile_stride,
                      svo_hit *hits_out, uint32_t *rgba_out);
+/* Primary rays of the rectangle / tile set as above, then n_secondary (1..4) rays from every pixel whose
+ * primary ray hit: origin hit.pos + normal * 2.5e-6 (shader.wgsl:276); ray 0 towards -normalize(sun_dir) (the
+ * shadow ray), ray k >= 1 along normalize(e) with e_i = float((h >> 10 i) & 1023) - 511.5,
+ * h = mix32((py * width + px) * 4 + k + 0x9E3779B9) (mix32: xorshift-multiply, see oracle/svo_oracle.c),
+ * negated if dot(normal, e) < 0.  secondary_out holds n_secondary * n records, ray-major
+ * (secondary_out[k * n + i] belongs to primary record i); pixels without a primary hit get the miss record
+ * {0, 0, 0, 0}.  Like the shadow ray, secondary rays bump the hit counters unless pause_adaptive.
+ * primary_out may be NULL.  Device pointers; asynchronous on the ctx stream. */
+int svo_render_secondary(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0,
+                         uint32_t tile_w, uint32_t tile_h, uint32_t n_secondary, svo_hit *primary_out,
+                         svo_hit *secondary_out);
+int svo_render_tiles_secondary(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t tile_w,
+                               uint32_t tile_h, uint32_t first_tile, uint32_t tile_stride,
+                               uint32_t n_secondary, svo_hit *primary_out, svo_hit *secondary_out);
 /* octree_ray over n explicit rays (6 floats each: pos.xyz, dir.xyz; device pointers). */
 int svo_trace_rays(svo_ctx *ctx, const float *rays, size_t n_rays, svo_hit *hits_out);
 

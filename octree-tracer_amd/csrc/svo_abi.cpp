@@ -249,7 +249,7 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         if (rc) return rc;
         rc = ensure_dev(ctx, &ctx->shade_shadow, &ctx->shade_shadow_bytes, n * sizeof(svo_hit));
         if (rc) return rc;
-        HIP_TRY(ctx, svo::launch_shadow_gen(a, (const float *)ctx->shade_aux, (float *)ctx->shade_rays, ctx->stream));
+        HIP_TRY(ctx, svo::launch_secondary_gen(a, (const float *)ctx->shade_aux, (float *)ctx->shade_rays, 1u, (uint32_t)n, ctx->stream));
         svo::WorkDesc rw{};
         rw.mode = 2;
         rw.n_items = (uint32_t)n;
@@ -261,6 +261,75 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         if (rc) return rc;
     }
     HIP_TRY(ctx, svo::launch_shade(a, shadows ? (const svo_hit *)ctx->shade_shadow : nullptr, rgba, ctx->stream));
+    return SVO_OK;
+}
+
+// Primary rays of `work`, then n_secondary rays from every hit pixel (ray 0: fs_main's shadow ray), traced as one
+// launch of explicit rays; records ray-major: secondary[k * n + record].
+int trace_secondary(svo_ctx *ctx, const svo::WorkDesc &work, uint32_t n_secondary, svo_hit *primary, svo_hit *secondary) {
+    if (!ctx->nodes) return fail(ctx, SVO_ERR_STATE, "svo_nodes_alloc / svo_nodes_bind_device not called");
+    if (!secondary) return fail(ctx, SVO_ERR_ARG, "secondary_out is NULL");
+    if (n_secondary < 1 || n_secondary > 4) return fail(ctx, SVO_ERR_ARG, "n_secondary must be 1..4");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    const size_t n = (size_t)work.n_rects * work.w * work.h;
+    if (n * n_secondary > (1u << 26)) return fail(ctx, SVO_ERR_ARG, "too many secondary rays for one call");
+    if (!primary) {
+        rc = ensure_dev(ctx, &ctx->shade_hits, &ctx->shade_hits_bytes, n * sizeof(svo_hit));
+        if (rc) return rc;
+        primary = (svo_hit *)ctx->shade_hits;
+    }
+    rc = ensure_dev(ctx, &ctx->shade_aux, &ctx->shade_aux_bytes, n * sizeof(float));
+    if (rc) return rc;
+    rc = ensure_dev(ctx, &ctx->shade_rays, &ctx->shade_rays_bytes, n * n_secondary * 6 * sizeof(float));
+    if (rc) return rc;
+    TraceOpts popt;
+    popt.aux_t = (float *)ctx->shade_aux;
+    rc = trace_launch(ctx, work, nullptr, primary, popt);
+    if (rc) return rc;
+    svo::TraceArgs a{};
+    a.nodes = ctx->nodes;
+    a.n_words = (uint32_t)ctx->capacity;
+    a.u = ctx->uniforms;
+    a.work = work;
+    a.hits = primary;
+    HIP_TRY(ctx, svo::launch_secondary_gen(a, (const float *)ctx->shade_aux, (float *)ctx->shade_rays, n_secondary, (uint32_t)n,
+                                           ctx->stream));
+    svo::WorkDesc rw{};
+    rw.mode = 2;
+    rw.n_items = (uint32_t)(n * n_secondary);
+    rw.bpr = rw.bprect = rw.tiles_x = 1;
+    TraceOpts sopt;
+    sopt.count_rays = true;  // like the shadow ray, which passes primary = true (shader.wgsl:276)
+    sopt.sched_slot = 1;
+    return trace_launch(ctx, rw, (const float *)ctx->shade_rays, secondary, sopt);
+}
+
+int make_tiles_work(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t first_tile,
+                    uint32_t tile_stride, svo::WorkDesc &work) {
+    if (!ctx->have_uniforms) return fail(ctx, SVO_ERR_STATE, "svo_set_uniforms not called");
+    if ((float)width != ctx->uniforms.dimensions[0] || (float)height != ctx->uniforms.dimensions[1])
+        return fail(ctx, SVO_ERR_ARG, "width/height differ from uniforms.dimensions");
+    if (tile_w == 0 || tile_h == 0 || width % tile_w || height % tile_h)
+        return fail(ctx, SVO_ERR_ARG, "frame must be a whole number of tiles");
+    if (tile_stride == 0) return fail(ctx, SVO_ERR_ARG, "tile_stride must be >= 1");
+    uint32_t tiles_x = width / tile_w, tiles = tiles_x * (height / tile_h);
+    work = svo::WorkDesc{};
+    work.mode = 1;
+    work.w = tile_w; work.h = tile_h;
+    work.bw_log2 = ctx->block_w_log2;
+    {
+        const uint32_t bw = 1u << work.bw_log2, bh = 64u >> work.bw_log2;
+        work.bpr = (tile_w + bw - 1) / bw;
+        work.bprect = work.bpr * ((tile_h + bh - 1) / bh);
+    }
+    work.n_rects = first_tile < tiles ? (tiles - first_tile + tile_stride - 1) / tile_stride : 0;
+    work.tiles_x = tiles_x;
+    work.first_tile = first_tile;
+    work.tile_stride = tile_stride;
+    uint64_t items = (uint64_t)work.n_rects * work.bprect * 64u;
+    if (items > (1u << 26)) return fail(ctx, SVO_ERR_ARG, "too many pixels for one call");
+    work.n_items = (uint32_t)items;
     return SVO_OK;
 }
 
@@ -555,30 +624,29 @@ int svo_render_host(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t x0, 
 int svo_render_tiles(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
                      uint32_t first_tile, uint32_t tile_stride, svo_hit *hits_out, uint32_t *rgba_out) {
     if (!ctx) return SVO_ERR_ARG;
-    if (!ctx->have_uniforms) return fail(ctx, SVO_ERR_STATE, "svo_set_uniforms not called");
-    if ((float)width != ctx->uniforms.dimensions[0] || (float)height != ctx->uniforms.dimensions[1])
-        return fail(ctx, SVO_ERR_ARG, "width/height differ from uniforms.dimensions");
-    if (tile_w == 0 || tile_h == 0 || width % tile_w || height % tile_h)
-        return fail(ctx, SVO_ERR_ARG, "frame must be a whole number of tiles");
-    if (tile_stride == 0) return fail(ctx, SVO_ERR_ARG, "tile_stride must be >= 1");
-    uint32_t tiles_x = width / tile_w, tiles = tiles_x * (height / tile_h);
-    svo::WorkDesc work{};
-    work.mode = 1;
-    work.w = tile_w; work.h = tile_h;
-    work.bw_log2 = ctx->block_w_log2;
-    {
-        const uint32_t bw = 1u << work.bw_log2, bh = 64u >> work.bw_log2;
-        work.bpr = (tile_w + bw - 1) / bw;
-        work.bprect = work.bpr * ((tile_h + bh - 1) / bh);
-    }
-    work.n_rects = first_tile < tiles ? (tiles - first_tile + tile_stride - 1) / tile_stride : 0;
-    work.tiles_x = tiles_x;
-    work.first_tile = first_tile;
-    work.tile_stride = tile_stride;
-    uint64_t items = (uint64_t)work.n_rects * work.bprect * 64u;
-    if (items > (1u << 26)) return fail(ctx, SVO_ERR_ARG, "too many pixels for one call");
-    work.n_items = (uint32_t)items;
+    svo::WorkDesc work;
+    int rc = make_tiles_work(ctx, width, height, tile_w, tile_h, first_tile, tile_stride, work);
+    if (rc) return rc;
     return trace_common(ctx, work, nullptr, hits_out, rgba_out);
+}
+
+int svo_render_secondary(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t tile_w,
+                         uint32_t tile_h, uint32_t n_secondary, svo_hit *primary_out, svo_hit *secondary_out) {
+    if (!ctx) return SVO_ERR_ARG;
+    svo::WorkDesc work;
+    int rc = make_rect_work(ctx, width, height, x0, y0, tile_w, tile_h, work);
+    if (rc) return rc;
+    return trace_secondary(ctx, work, n_secondary, primary_out, secondary_out);
+}
+
+int svo_render_tiles_secondary(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
+                               uint32_t first_tile, uint32_t tile_stride, uint32_t n_secondary, svo_hit *primary_out,
+                               svo_hit *secondary_out) {
+    if (!ctx) return SVO_ERR_ARG;
+    svo::WorkDesc work;
+    int rc = make_tiles_work(ctx, width, height, tile_w, tile_h, first_tile, tile_stride, work);
+    if (rc) return rc;
+    return trace_secondary(ctx, work, n_secondary, primary_out, secondary_out);
 }
 
 int svo_trace_rays(svo_ctx *ctx, const float *rays, size_t n_rays, svo_hit *hits_out) {

@@ -76,7 +76,8 @@ constexpr uint32_t kOrderHistWords = 64 * 16;      // chunk histograms of the sc
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
                        uint32_t cap, bool build_schedule, hipStream_t stream);
 
-hipError_t launch_shadow_gen(const TraceArgs &args, const float *aux_t, float *rays, hipStream_t stream);
+hipError_t launch_secondary_gen(const TraceArgs &args, const float *aux_t, float *rays, uint32_t n_secondary, uint32_t n_records,
+                                hipStream_t stream);
 hipError_t launch_shade(const TraceArgs &args, const svo_hit *shadow_hits, uint32_t *rgba, hipStream_t stream);
 hipError_t launch_diag_gather(const uint32_t *buf, uint32_t n_words, uint32_t stride_words, uint32_t n_loads, uint32_t *sink,
                               hipStream_t stream);

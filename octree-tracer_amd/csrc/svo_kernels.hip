@@ -932,25 +932,38 @@ __global__ __launch_bounds__(kOrderThreads) void strip_order_kernel(const uint8_
 
 // ---------------------------------------------------------------------------------------------
 // fs_main's shading (shader.wgsl:261-304) on top of the hit records.  The shadow ray of :275-280 is traced
-// by the same trace kernels as an explicit ray (svo_trace_rays path): shadow_gen_kernel writes one ray per
+// by the same trace kernels as an explicit ray (svo_trace_rays path): secondary_gen_kernel writes one ray per
 // pixel (a ray that starts outside the cube pointing away -- an immediate miss -- for pixels that need none),
 // the trace kernel produces a second set of records, and shade_kernel combines both into RGBA8.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float code_to_normal(uint32_t c) { return c == 1u ? 1.0f : (c == 2u ? -1.0f : 0.0f); }
 
-__global__ __launch_bounds__(256) void shadow_gen_kernel(TraceArgs a, const float *aux_t, float *rays) {
+// Directions of the extra secondary rays (benchmark config 5; the reference itself only has the shadow ray):
+// three 10-bit fields of an integer hash of (frame pixel id, k) as half-integer components in (-512, 512),
+// normalised like every other direction, mirrored into the hemisphere of the hit normal.  Integer -> float
+// conversions are exact and the operation order is fixed, so the oracle produces the same bits.
+__device__ __forceinline__ uint32_t mix32(uint32_t a) {
+    a ^= a >> 16; a *= 0x7feb352du; a ^= a >> 15; a *= 0x846ca68bu; a ^= a >> 16;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void secondary_gen_kernel(TraceArgs a, const float *aux_t, float *rays, uint32_t n_secondary,
+                                                            uint32_t n_records) {
     const float sl = sqrtf((a.u.sun_dir[0] * a.u.sun_dir[0] + a.u.sun_dir[1] * a.u.sun_dir[1]) + a.u.sun_dir[2] * a.u.sun_dir[2]);
     const float s0 = a.u.sun_dir[0] / sl, s1 = a.u.sun_dir[1] / sl, s2 = a.u.sun_dir[2] / sl;  // normalize(u.sun_dir.xyz)
+    const uint32_t width = (uint32_t)a.u.dimensions[0];
     for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < a.work.n_items; q += gridDim.x * 256u) {
         Item it = decode_item(a.work, q);
         if (!it.valid) continue;
         const uint4 rec = reinterpret_cast<const uint4 *>(a.hits)[it.out];
-        float o[6] = {5.0f, 5.0f, 5.0f, 1.0f, 1.0f, 1.0f};  // never enters the cube
-        if ((rec.z >> 16) & 1u) {
+        const bool hit = (rec.z >> 16) & 1u;
+        float org[3] = {5.0f, 5.0f, 5.0f};  // no hit: a ray that never enters the cube
+        float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
+        if (hit) {
             RayIn r = gen_ray(a.u, it.px, it.py);
             float pos[3], dir[3], dist;
             ray_enter(r, pos, dir, dist);
-            const float n0 = code_to_normal(rec.w & 3u), n1 = code_to_normal((rec.w >> 2) & 3u), n2 = code_to_normal((rec.w >> 4) & 3u);
+            n0 = code_to_normal(rec.w & 3u); n1 = code_to_normal((rec.w >> 2) & 3u); n2 = code_to_normal((rec.w >> 4) & 3u);
             float h0 = pos[0], h1 = pos[1], h2 = pos[2];  // HitInfo.pos = voxel_pos of the last find_voxel
             if ((rec.z & 0xFFu) != 0u) {
                 const float t = aux_t[it.out];
@@ -958,12 +971,27 @@ __global__ __launch_bounds__(256) void shadow_gen_kernel(TraceArgs a, const floa
                 h1 = pos[1] + dir[1] * t - n1 * 0.000002f;
                 h2 = pos[2] + dir[2] * t - n2 * 0.000002f;
             }
-            o[0] = h0 + n0 * 0.0000025f; o[1] = h1 + n1 * 0.0000025f; o[2] = h2 + n2 * 0.0000025f;  // :276
-            o[3] = -s0; o[4] = -s1; o[5] = -s2;
+            org[0] = h0 + n0 * 0.0000025f; org[1] = h1 + n1 * 0.0000025f; org[2] = h2 + n2 * 0.0000025f;  // :276
         }
-        float *dst = rays + 6ull * it.out;
-#pragma unroll
-        for (int k = 0; k < 6; k++) dst[k] = o[k];
+        for (uint32_t k = 0; k < n_secondary; k++) {
+            float d0 = 1.0f, d1 = 1.0f, d2 = 1.0f;
+            if (hit) {
+                if (k == 0u) {
+                    d0 = -s0; d1 = -s1; d2 = -s2;  // the shadow ray, shader.wgsl:276
+                } else {
+                    const uint32_t hsh = mix32((it.py * width + it.px) * 4u + k + 0x9E3779B9u);
+                    float e0 = (float)(int)(hsh & 1023u) - 511.5f, e1 = (float)(int)((hsh >> 10) & 1023u) - 511.5f,
+                          e2 = (float)(int)((hsh >> 20) & 1023u) - 511.5f;
+                    const float len = sqrtf((e0 * e0 + e1 * e1) + e2 * e2);
+                    e0 = e0 / len; e1 = e1 / len; e2 = e2 / len;
+                    const bool flip = (n0 * e0 + n1 * e1) + n2 * e2 < 0.0f;
+                    d0 = flip ? -e0 : e0; d1 = flip ? -e1 : e1; d2 = flip ? -e2 : e2;
+                }
+            }
+            float *dst = rays + 6ull * ((uint64_t)k * n_records + it.out);
+            dst[0] = org[0]; dst[1] = org[1]; dst[2] = org[2];
+            dst[3] = d0; dst[4] = d1; dst[5] = d2;
+        }
     }
 }
 
@@ -1004,11 +1032,12 @@ __global__ __launch_bounds__(256) void shade_kernel(TraceArgs a, const svo_hit *
     }
 }
 
-hipError_t launch_shadow_gen(const TraceArgs &args, const float *aux_t, float *rays, hipStream_t stream) {
+hipError_t launch_secondary_gen(const TraceArgs &args, const float *aux_t, float *rays, uint32_t n_secondary, uint32_t n_records,
+                                hipStream_t stream) {
     (void)hipGetLastError();
     uint32_t blocks = (args.work.n_items + 255u) / 256u;
     if (blocks > 4096u) blocks = 4096u;
-    hipLaunchKernelGGL(shadow_gen_kernel, dim3(blocks), dim3(256), 0, stream, args, aux_t, rays);
+    hipLaunchKernelGGL(secondary_gen_kernel, dim3(blocks), dim3(256), 0, stream, args, aux_t, rays, n_secondary, n_records);
     return hipGetLastError();
 }
 

@@ -118,6 +118,32 @@ class Render:
                                               hits.data_ptr(), rgba.data_ptr() if rgba is not None else None))
         return hits
 
+    def render_secondary(self, n_secondary, tile=None, hits=None, secondary=None):
+        """Primary rays plus n_secondary rays per hit pixel (svo_render_secondary): returns (primary records,
+        secondary records [n_secondary * n_pixels, ray-major]) as device tensors; asynchronous."""
+        w, h = self.size
+        x0, y0, tw, th = tile if tile is not None else (0, 0, w, h)
+        if hits is None:
+            hits = self.alloc_hits(tw * th)
+        if secondary is None:
+            secondary = self.alloc_hits(n_secondary * tw * th)
+        self.gpu.check(lib().svo_render_secondary(self.gpu._h, w, h, x0, y0, tw, th, n_secondary, hits.data_ptr(),
+                                                  secondary.data_ptr()))
+        return hits, secondary
+
+    def render_tiles_secondary(self, tile_w, tile_h, first_tile, tile_stride, n_secondary, hits=None, secondary=None):
+        """render_tiles with secondary rays: this rank's tiles, contiguous; secondary ray-major over them."""
+        w, h = self.size
+        n_tiles_total = (w // tile_w) * (h // tile_h)
+        n_mine = max(0, (n_tiles_total - first_tile + tile_stride - 1) // tile_stride)
+        if hits is None:
+            hits = self.alloc_hits(n_mine * tile_w * tile_h)
+        if secondary is None:
+            secondary = self.alloc_hits(n_secondary * n_mine * tile_w * tile_h)
+        self.gpu.check(lib().svo_render_tiles_secondary(self.gpu._h, w, h, tile_w, tile_h, first_tile, tile_stride,
+                                                        n_secondary, hits.data_ptr(), secondary.data_ptr()))
+        return hits, secondary
+
     def render_host(self, tile=None, rgba=False):
         """Blocking variant with host results: hit records (numpy structured array, tile-local row-major)
         and, with rgba=True, also the shaded RGBA8 image of fs_main (uint8 [h, w, 4])."""

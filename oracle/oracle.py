@@ -75,6 +75,8 @@ def lib():
     L.oracle_trace_rays.argtypes = [vp, C.c_size_t, C.c_uint32, vp, C.c_size_t, vp, vp, C.c_int]
     L.oracle_trace_frame.argtypes = [vp, C.c_size_t, C.POINTER(Uniforms), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
     L.oracle_shade_frame.argtypes = [vp, C.c_size_t, C.POINTER(Uniforms), C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.oracle_secondary_frame.argtypes = [vp, C.c_size_t, C.POINTER(Uniforms), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
+                                         vp, vp, C.c_int]
     L.oracle_count_frame.argtypes = [vp, C.c_size_t, C.POINTER(Uniforms), C.c_int, C.c_int, C.c_int, C.c_int]
     L.oracle_scan.argtypes = [vp, C.c_size_t, C.c_uint32, vp, vp, C.c_size_t]
     _lib = L
@@ -227,6 +229,17 @@ def shade_frame(nodes, u, tile=None, threads=1):
     rgba = np.empty((h, w, 4), dtype=np.float32)
     lib().oracle_shade_frame(_ptr(nodes), nodes.size, C.byref(u), x0, y0, w, h, _ptr(rgba), threads)
     return rgba
+
+
+def secondary_frame(nodes, u, n_secondary, tile=None, threads=1):
+    """Primary records [h, w] and secondary records [n_secondary, h, w] (svo_render_secondary's definition)."""
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+    W, H = int(u.dimensions[0]), int(u.dimensions[1])
+    x0, y0, w, h = tile if tile else (0, 0, W, H)
+    prim = np.empty((h, w), dtype=HIT_DTYPE)
+    sec = np.empty((n_secondary, h, w), dtype=HIT_DTYPE)
+    lib().oracle_secondary_frame(_ptr(nodes), nodes.size, C.byref(u), x0, y0, w, h, n_secondary, _ptr(prim), _ptr(sec), threads)
+    return prim, sec
 
 
 def count_frame(nodes, u, tile=None):

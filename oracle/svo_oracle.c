@@ -733,6 +733,66 @@ void oracle_shade_frame(const uint32_t *nodes, size_t n_nodes, const oracle_unif
     par_for(shade_fn, &j, (size_t)h, 4, n_threads);
 }
 
+/* Benchmark config 5 (no reference counterpart beyond the shadow ray): per hit pixel, ray 0 = the shadow ray
+ * of shader.wgsl:275-280 and rays 1.. from the same origin along hashed directions (include/svo_hip.h,
+ * svo_render_secondary).  Pixels without a hit trace a ray that never enters the cube. */
+static uint32_t mix32(uint32_t a) {
+    a ^= a >> 16; a *= 0x7feb352du; a ^= a >> 15; a *= 0x846ca68bu; a ^= a >> 16;
+    return a;
+}
+
+typedef struct {
+    frame_job f;
+    uint32_t n_secondary;
+    oracle_hit *secondary;
+} secondary_job;
+
+static void secondary_fn(void *arg, size_t b, size_t e) {
+    secondary_job *sj = (secondary_job *)arg;
+    frame_job *j = &sj->f;
+    const oracle_uniforms *u = j->u;
+    trace_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.nodes = j->nodes; c.n_nodes = j->n_nodes; c.flags = u->flags; c.visits = j->visits;
+    float sl = sqrtf((u->sun_dir[0]*u->sun_dir[0] + u->sun_dir[1]*u->sun_dir[1]) + u->sun_dir[2]*u->sun_dir[2]);
+    float sun[3] = {u->sun_dir[0] / sl, u->sun_dir[1] / sl, u->sun_dir[2] / sl};
+    uint32_t width = (uint32_t)u->dimensions[0];
+    size_t n = (size_t)j->w * (size_t)j->h;
+    for (size_t row = b; row < e; row++)
+        for (int col = 0; col < j->w; col++) {
+            int px = j->x0 + col, py = j->y0 + (int)row;
+            ray_t r = gen_ray(u, px, py);
+            hitinfo_t h = octree_ray(&c, &r, 1);
+            size_t i = row * (size_t)j->w + (size_t)col;
+            if (j->out) j->out[i] = pack_hit(&h);
+            for (uint32_t k = 0; k < sj->n_secondary; k++) {
+                ray_t sr = {{5.0f, 5.0f, 5.0f}, {1.0f, 1.0f, 1.0f}};
+                if (h.hit) {
+                    for (int a = 0; a < 3; a++) sr.pos[a] = h.pos[a] + h.normal[a] * 0.0000025f;
+                    if (k == 0) {
+                        for (int a = 0; a < 3; a++) sr.dir[a] = -sun[a];
+                    } else {
+                        uint32_t hs = mix32(((uint32_t)py * width + (uint32_t)px) * 4u + k + 0x9E3779B9u);
+                        float d[3] = {(float)(int)(hs & 1023u) - 511.5f, (float)(int)((hs >> 10) & 1023u) - 511.5f,
+                                      (float)(int)((hs >> 20) & 1023u) - 511.5f};
+                        float len = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+                        for (int a = 0; a < 3; a++) d[a] = d[a] / len;
+                        int flip = (h.normal[0] * d[0] + h.normal[1] * d[1]) + h.normal[2] * d[2] < 0.0f;
+                        for (int a = 0; a < 3; a++) sr.dir[a] = flip ? -d[a] : d[a];
+                    }
+                }
+                hitinfo_t sh = octree_ray(&c, &sr, 1);
+                sj->secondary[(size_t)k * n + i] = pack_hit(&sh);
+            }
+        }
+}
+
+void oracle_secondary_frame(const uint32_t *nodes, size_t n_nodes, const oracle_uniforms *u, int x0, int y0, int w,
+                            int h, uint32_t n_secondary, oracle_hit *primary, oracle_hit *secondary, int n_threads) {
+    secondary_job sj = {{nodes, n_nodes, u, x0, y0, w, h, primary, NULL, NULL, NULL}, n_secondary, secondary};
+    par_for(secondary_fn, &sj, (size_t)h, 4, n_threads);
+}
+
 void oracle_count_frame(uint32_t *nodes, size_t n_nodes, const oracle_uniforms *u, int x0, int y0,
                         int w, int h) {
     uint32_t *visits = (uint32_t *)calloc(n_nodes ? n_nodes : 1, sizeof(uint32_t));

@@ -116,6 +116,9 @@ void oracle_shade_frame(const uint32_t *nodes, size_t n_nodes, const oracle_unif
 /* Sequential semantic of the hit-counter side effect (shader.wgsl:157-161): every word visited
  * by a primary-ray descent (including shadow rays, which pass primary=true, :276) gets +1,
  * saturating at 15.  Applies the increments of the given tile to nodes in place. */
+/* svo_render_secondary's definition on the CPU: primary records + n_secondary * w * h records, ray-major */
+void oracle_secondary_frame(const uint32_t *nodes, size_t n_nodes, const oracle_uniforms *u, int x0, int y0, int w,
+                            int h, uint32_t n_secondary, oracle_hit *primary, oracle_hit *secondary, int n_threads);
 void oracle_count_frame(uint32_t *nodes, size_t n_nodes, const oracle_uniforms *u, int x0, int y0,
                         int w, int h);
 

@@ -380,6 +380,92 @@ def test_config3_rsvo_shell(pkg, gpu, O):
             assert_hits_equal(got, O.trace_frame(words, u, threads=8), f"rsvo shell depth {depth}")
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_secondary_rays_per_hit_pixel(pkg, gpu, O, monu9_words, small_words, variant):
+    """svo_render_secondary: ray 0 is fs_main's shadow ray (shader.wgsl:275-280), rays 1..3 share its origin;
+    records are bit-exact against the oracle, the tile-sharded call equals the full frame, and ray 0 decides
+    exactly the pixels the shaded image shows in shadow."""
+    gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+    for words, pose in ((monu9_words, ((0.1, 0.2, -1.5), (0.0, 0.0, 1.5))), (monu9_words, ((0.02, 0.31, 0.05), (0.3, -0.2, 1.0))),
+                        (small_words, ((0.9, 0.8, -1.1), (-0.9, -0.8, 1.1)))):
+        W, H = 256, 128
+        u = O.make_uniforms(pos=pose[0], look=pose[1], width=W, height=H, flags=O.F_PAUSE_ADAPTIVE | O.F_SHADOWS)
+        render = pkg.Render(gpu, (W, H), words, capacity=words.size)
+        set_uniforms_from_oracle(render, u)
+        oprim, osec = O.secondary_frame(words, u, 4, threads=8)
+        for frame in range(2):
+            prim, sec = render.render_secondary(4)
+            gpu.sync()
+        assert_hits_equal(pkg.render.hits_to_numpy(prim), oprim, "primary records of the secondary call")
+        sec = pkg.render.hits_to_numpy(sec).reshape(4, H, W)
+        for k in range(4):
+            assert_hits_equal(sec[k], osec[k], f"secondary ray {k}")
+        hit = ((oprim["info"] >> 16) & 1).astype(bool)
+        assert hit.any() and not hit.all()
+        assert (sec["value"][:, ~hit] == 0).all() and (((sec["info"] >> 16) & 1)[:, ~hit] == 0).all()
+        # fewer rays: a prefix of the same rays
+        _, sec2 = render.render_secondary(2)
+        gpu.sync()
+        assert_hits_equal(pkg.render.hits_to_numpy(sec2).reshape(2, H, W), osec[:2], "n_secondary = 2")
+        # tile sharding: two "ranks" with interleaved 64x8 tiles reassemble to the full frame
+        tw, th = 64, 8
+        full = np.empty((4, H, W), dtype=pkg.HIT_DTYPE)
+        for rank in range(2):
+            _, part = render.render_tiles_secondary(tw, th, rank, 2, 4)
+            gpu.sync()
+            n_mine = pkg.sharding.local_tile_count(W, H, tw, th, rank, 2)
+            part = pkg.render.hits_to_numpy(part).reshape(4, n_mine, th, tw)
+            for j in range(n_mine):
+                t = rank + 2 * j
+                ty, tx = divmod(t, W // tw)
+                full[:, ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = part[:, j]
+        assert_hits_equal(full, osec, "secondary rays, tile-sharded")
+        # a rectangle inside the frame
+        _, rect = render.render_secondary(3, tile=(40, 16, 100, 50))
+        gpu.sync()
+        assert_hits_equal(pkg.render.hits_to_numpy(rect).reshape(3, 50, 100), osec[:3, 16:66, 40:140], "secondary rays of a rectangle")
+    with pytest.raises(pkg.SvoError):
+        render.render_secondary(5)
+
+
+def test_config3_block_instanced_shell(pkg, gpu, O):
+    """Config 3 stand-in as SURVEY 8d describes it: an .rsvo shell whose leaves reference the eight 16^3 block
+    models (cpu_octree.rs:37, world.rs:19-58), expanded by the streaming loop's rule (svo_world_expand) to
+    shell depth + 4 levels, then traced."""
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "blocks_vox.npz"))
+    world = pkg.World.new("")
+    for i, name in enumerate(pkg.world.BLOCK_NAMES):
+        world.insert(i + 1, pkg.CpuOctree.from_voxels(16, z[name + "_xyzi"], z[name + "_palette"]))
+        world.generate_mip_tree(i + 1)
+    depth = 5
+    tree = pkg.CpuOctree.new(0)
+    n = 1 << depth
+    ax = (np.arange(n) + 0.5) / n * 2 - 1
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    r = np.sqrt(X * X + Y * Y + Z * Z)
+    for i, j, k in np.argwhere(np.abs(r - 0.75) < 1.0 / n):
+        tree.put_in_voxel((float(ax[i]), float(ax[j]), float(ax[k])), pkg.Voxel(1, 1, 1), depth)
+    world.insert(0, pkg.CpuOctree.load_octree(tree.to_rsvo(), depth))
+    world.generate_mip_tree(0)
+    octree = world.root_octree()
+    world.expand(octree, max_depth=depth + 4)
+    words = octree.raw_data()
+    assert pkg.scenes.max_depth(words) == depth + 4 and words.size > 3_000_000
+    u = O.make_uniforms(pos=(0.3, 0.4, -1.6), look=(-0.2, -0.3, 1.5), width=480, height=270, flags=O.F_PAUSE_ADAPTIVE)
+    want = O.trace_frame(words, u, threads=8)
+    assert ((want["info"] >> 16) & 1).mean() > 0.10
+    for variant in VARIANTS:
+        assert_hits_equal(_render(pkg, gpu, words, u, variant), want, "block-instanced shell")
+    # the view-limited expansion is a prefix-closed subtree of the same world: still a well-formed array
+    lod = world.root_octree()
+    world.expand(lod, max_depth=depth + 4, cam=(0.3, 0.4, -1.6), lod_c=40.0)
+    lw = lod.raw_data()
+    assert 8 < lw.size < words.size
+    assert_hits_equal(_render(pkg, gpu, lw, u, 1), O.trace_frame(lw, u, threads=8), "block-instanced shell, LOD expansion")
+
+
 def test_config5_fractal_depth20(pkg, gpu, O):
     """Config 5 family: depth-20 fractal (voxel 1.9e-6 < the reference's 2e-6 nudge, SURVEY section 0.5: the
     images are not meaningful but parity with the oracle stays exact), primary frame plus secondary rays
@@ -411,6 +497,12 @@ def test_config5_fractal_depth20(pkg, gpu, O):
         got = pkg.render.hits_to_numpy(render.trace_rays(torch.from_numpy(rays).cuda()))
         gpu.sync()
         assert_hits_equal(got, O.trace_rays(words, rays, threads=8), "fractal secondary rays")
+        # config 5 proper: 4 secondary rays per hit pixel (shadow ray + 3 hashed directions), both layouts
+        oprim, osec = O.secondary_frame(words, u, 4, threads=8)
+        prim, sec = render.render_secondary(4)
+        gpu.sync()
+        assert_hits_equal(pkg.render.hits_to_numpy(prim), oprim, "fractal primary (secondary call)")
+        assert_hits_equal(pkg.render.hits_to_numpy(sec), osec, "fractal 4 secondary rays / pixel")
         gpu.set_option(pkg.gpu.OPT_VARIANT, 0)
         assert_hits_equal(_render(pkg, gpu, words, u, 0), want, "fractal depth 20, general kernel")
     finally:
