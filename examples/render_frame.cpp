@@ -18,6 +18,23 @@ int main(int argc, char **argv) {
                 }
     const std::vector<uint32_t> words = cpu.to_octree_words();
     std::printf("tree: %zu words\n", words.size());
+    // a world whose root chunk instances that tree as block 1 in two octants (world.rs:5-9, cpu_octree.rs:78-90)
+    svo::World world;
+    world.insert(1, std::move(cpu));
+    world.generate_mip_tree(1);
+    {
+        svo::CpuOctree root;
+        const float a[3] = {-0.5f, -0.5f, -0.5f}, b[3] = {0.5f, 0.5f, 0.5f};
+        root.put_in_block(a, 1, 1);
+        root.put_in_block(b, 1, 1);
+        world.insert(0, std::move(root));
+    }
+    const svo::Voxel top = world.generate_mip_tree(0);
+    {
+        svo::Octree full = world.root_octree();
+        world.expand(full, 4);
+        std::printf("world: %zu words fully expanded, top mip (%u, %u, %u)\n", full.len(), top.r, top.g, top.b);
+    }
     if (argc > 1 && !std::strcmp(argv[1], "--host-only")) return 0;
     try {
         svo::Gpu gpu(0);
@@ -39,7 +56,19 @@ int main(int argc, char **argv) {
         compute.update(octree);
         auto lists = compute.read_lists();
         std::printf("scan: %zu to subdivide, %zu to unsubdivide\n", lists.first.size(), lists.second.size());
-        return n_hit > 0 ? 0 : 2;
+        // the streaming loop of App::update (app.rs:94-118) over the world: the device tree grows from the root group
+        svo::Octree streamed = world.root_octree();
+        size_t subdivided = 0;
+        for (int frame = 0; frame < 8; frame++) {
+            render.write_nodes(streamed.raw_data(), streamed.len());
+            render.render_host(hits.data());
+            compute.update(streamed);
+            auto l = compute.read_lists();
+            subdivided += world.process_subdivision(l.first, streamed);
+            world.process_unsubdivision(l.second, streamed);
+        }
+        std::printf("streaming: %zu subdivisions, device tree %zu words\n", subdivided, streamed.len());
+        return n_hit > 0 && subdivided > 0 ? 0 : 2;
     } catch (const svo::Error &e) {
         std::fprintf(stderr, "svo error %d: %s\n", e.status, e.what());
         return 1;

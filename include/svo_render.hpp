@@ -87,7 +87,20 @@ class CpuOctree {  // cpu_octree.rs:17-273
         svo_cpu_octree_generate_mips(t_, top);
         return Voxel{top[0], top[1], top[2]};
     }
+    void put_in_block(const float pos[3], uint32_t block_id, uint32_t depth) { svo_cpu_octree_put_in_block(t_, pos, block_id, depth); }
+    std::vector<uint8_t> bin() const {  // CpuOctree::bin, :262-264
+        std::vector<uint8_t> b(svo_cpu_octree_bin(t_, nullptr, 0));
+        svo_cpu_octree_bin(t_, b.data(), b.size());
+        return b;
+    }
+    static CpuOctree from_bin(const std::vector<uint8_t> &bin) {  // :266-272
+        char err[256] = {0};
+        svo_cpu_octree *t = svo_cpu_octree_from_bin(bin.data(), bin.size(), err, sizeof err);
+        if (!t) throw Error(SVO_ERR_ARG, err);
+        return CpuOctree(t);
+    }
     svo_cpu_octree *raw() const { return t_; }
+    svo_cpu_octree *release() { return std::exchange(t_, nullptr); }  // hand the tree to a World
 
   private:
     explicit CpuOctree(svo_cpu_octree *t) : t_(t) {}
@@ -117,9 +130,74 @@ class Octree {  // octree.rs:43-162
         if (rc < 0) throw Error(SVO_ERR_STATE, "Tried to unsubdivide a node without position!");
         return rc == 0;
     }
+    svo_octree *raw() const { return o_; }
 
   private:
     svo_octree *o_;
+};
+
+class World {  // world.rs:5-336: chunk table with block instancing
+  public:
+    struct Found { uint32_t chunk; size_t index; uint32_t depth; float pos[3]; };
+    explicit World(const std::string &path = "") : w_(svo_world_new(path.c_str())) {}
+    static World load_world(const std::string &path) {  // :159-174
+        char err[256] = {0};
+        svo_world *w = svo_world_load(path.c_str(), err, sizeof err);
+        if (!w) throw Error(SVO_ERR_ARG, err);
+        return World(w);
+    }
+    ~World() { svo_world_free(w_); }
+    World(World &&o) noexcept : w_(std::exchange(o.w_, nullptr)) {}
+    World(const World &) = delete;
+    void insert(uint32_t id, CpuOctree &&chunk) { check(svo_world_insert(w_, id, chunk.release())); }  // chunks.insert
+    bool remove(uint32_t id) { return svo_world_remove(w_, id) == 0; }
+    bool contains(uint32_t id) const { return svo_world_chunk(w_, id) != nullptr; }
+    Found find_voxel(const float pos[3], int64_t max_depth = -1) const {  // :201-232; the reference panics on a missing chunk
+        Found f{};
+        uint64_t index = 0;
+        check(svo_world_find_voxel(w_, pos, max_depth, &f.chunk, &index, &f.depth, f.pos));
+        f.index = size_t(index);
+        return f;
+    }
+    Voxel generate_mip_tree(uint32_t id) {  // :234-336
+        uint8_t top[3];
+        check(svo_world_generate_mip_tree(w_, id, top));
+        return Voxel{top[0], top[1], top[2]};
+    }
+    void save_chunk(uint32_t id) { check(svo_world_save_chunk(w_, id)); }  // :176-184
+    void load_chunk(uint32_t id) { check(svo_world_load_chunk(w_, id)); }  // :186-198, synchronous
+    Octree root_octree() const {  // App::new, app.rs:47-48
+        uint8_t rgb[24];
+        const svo_cpu_octree *root = svo_world_chunk(w_, 0);
+        if (!root) throw Error(SVO_ERR_STATE, "world has no root chunk");
+        svo_cpu_octree_get_node_mask(root, 0, rgb);
+        Voxel mask[8];
+        for (int i = 0; i < 8; i++) mask[i] = Voxel{rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
+        return Octree(mask);
+    }
+    // process_subdivision / process_unsubdivision over the lists Compute::read_lists returns (adaptive.rs:29-61, 93-121)
+    size_t process_subdivision(const std::vector<uint32_t> &list, Octree &octree) {
+        const int64_t n = svo_adaptive_subdivide(w_, octree.raw(), list.data(), list.size(), nullptr);
+        check(n < 0 ? -1 : 0);
+        return size_t(n);
+    }
+    size_t process_unsubdivision(const std::vector<uint32_t> &list, Octree &octree) {
+        const int64_t n = svo_adaptive_unsubdivide(w_, octree.raw(), list.data(), list.size());
+        check(n < 0 ? -1 : 0);
+        return size_t(n);
+    }
+    uint64_t expand(Octree &octree, uint32_t max_depth, const float *cam = nullptr, float lod_c = 0.0f,
+                    uint64_t max_words = 1ull << 27) {
+        return svo_world_expand(w_, octree.raw(), max_depth, cam, cam ? lod_c : 0.0f, max_words);
+    }
+    svo_world *raw() const { return w_; }
+
+  private:
+    explicit World(svo_world *w) : w_(w) {}
+    void check(int rc) const {
+        if (rc < 0) throw Error(SVO_ERR_STATE, svo_world_last_error(w_));
+    }
+    svo_world *w_;
 };
 
 class Render {  // render.rs:3-285
@@ -157,6 +235,10 @@ class Render {  // render.rs:3-285
     // Render::render: one pass over every pixel (render.rs:217-284).  Device pointers; asynchronous.
     void render(svo_hit *hits_dev, uint32_t *rgba_dev = nullptr) {
         gpu_.check(svo_render(gpu_.ctx(), width, height, 0, 0, width, height, hits_dev, rgba_dev));
+    }
+    // primary rays + n_secondary rays per hit pixel (ray 0: the shadow ray of shader.wgsl:275-280); device pointers
+    void render_secondary(uint32_t n_secondary, svo_hit *primary_dev, svo_hit *secondary_dev) {
+        gpu_.check(svo_render_secondary(gpu_.ctx(), width, height, 0, 0, width, height, n_secondary, primary_dev, secondary_dev));
     }
     // same, results copied to host memory (blocking)
     void render_host(svo_hit *hits, uint32_t *rgba = nullptr) {

@@ -50,7 +50,7 @@ class CpuOctree:
                                                           palette.ctypes.data, err, 256), err)
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._owned:
+        if getattr(self, "_h", None) and self._owned and lib is not None:  # (module globals are gone at interpreter exit)
             lib().svo_cpu_octree_free(self._h)
         self._h = None
 

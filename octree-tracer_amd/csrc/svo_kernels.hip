@@ -379,7 +379,7 @@ __device__ __forceinline__ float copysign_bits(float mag, float sgn) {
 // forms above are proven for.  pos is the entry point (|pos| <= 2 always holds for rays that enter).
 __device__ __forceinline__ bool clean_component(float p, float d) {
     float ap = fabsf(p), ad = fabsf(d);
-    bool p_ok = (ap <= 2.0f) && (p == 0.0f || ap >= 9.313225746154785e-10f);  // 2^-30
+    bool p_ok = ap <= 2.0f;  // any magnitude below: scaling by 2^23 is exact, and A = (C - P) + H is 0 or >= 2^-26
     bool d_ok = (ad >= 9.094947017729282e-13f) && (ad <= 1099511627776.0f);     // 2^-40 .. 2^40
     return p_ok && d_ok;  // NaN fails both
 }
@@ -1137,7 +1137,9 @@ hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t
 // `build_schedule`, the strip lists for the next frames.
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
                        uint32_t cap, bool build_schedule, hipStream_t stream) {
-    uint32_t blocks = cost ? (n_strips + 3u) / 4u : 16u;
+    // without the cost pass the launch only re-arms counters and traces deferred rays: normally none, but a frame
+    // full of them (every ray NaN / extreme) must not crawl through 16 workgroups
+    uint32_t blocks = cost ? (n_strips + 3u) / 4u : 256u;
     if (blocks > 2048u) blocks = 2048u;
     if (blocks < 16u) blocks = 16u;
     hipLaunchKernelGGL(post_kernel, dim3(blocks), dim3(256), 0, stream, args, li.counters, (const uint32_t *)li.defer,

@@ -63,4 +63,5 @@ class Gpu:
             self._h = None
 
     def __del__(self):
-        self.close()
+        if lib is not None:  # (module globals are gone at interpreter exit)
+            self.close()

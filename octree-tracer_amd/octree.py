@@ -60,9 +60,9 @@ class Octree:
         return cls(_handle=lib().svo_octree_from_words(words.ctypes.data, words.size))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (module globals are gone at interpreter exit)
             lib().svo_octree_free(self._h)
-            self._h = None
+        self._h = None
 
     def __len__(self):
         return lib().svo_octree_len(self._h)

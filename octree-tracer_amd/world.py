@@ -42,9 +42,9 @@ class World:
         return cls(path, _handle=h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (module globals are gone at interpreter exit)
             lib().svo_world_free(self._h)
-            self._h = None
+        self._h = None
 
     def _check(self, rc):
         if rc < 0:

@@ -22,6 +22,7 @@ def test_cpp_host_compiles_and_builds_tree(tmp_path, pkg):
     exe = _build(tmp_path, pkg)
     out = subprocess.run([exe, "--host-only"], capture_output=True, text=True, check=True).stdout
     assert "tree: 456 words" in out  # 8 * (1 + 56 interior nodes)
+    assert "world: 920 words fully expanded" in out  # root group + two instances of the 456-word block
 
 
 @pytest.mark.gpu
@@ -29,4 +30,4 @@ def test_cpp_host_renders(tmp_path, pkg, gpu):
     exe = _build(tmp_path, pkg)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "hits" in r.stdout and "scan:" in r.stdout
+    assert "hits" in r.stdout and "scan:" in r.stdout and "streaming:" in r.stdout

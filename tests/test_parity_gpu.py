@@ -606,3 +606,35 @@ def test_lattice_rays_ties_and_boundaries(pkg, gpu, O, monu9_words, variant):
                 multi = np.isin(want["normal_bits"], [0b000101, 0b000110, 0b001001, 0b001010, 0b010001, 0b010010,
                                                       0b100001, 0b100010, 0b010100, 0b011000, 0b100100, 0b101000])
                 assert multi.any(), "the set should contain steps that tie on two axes"
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_tiny_origin_components(pkg, gpu, O, monu9_words, variant):
+    """Origins with components far below the voxel size -- exactly 0, +-1e-12, +-1e-30, subnormal -- and a camera
+    sitting exactly on the x = 0 / y = 0 centre planes (its matrix inverse yields |pos| ~ 1e-17): these take the
+    fast path of the STACK kernel (no lower bound on |pos|) and must stay bit-exact."""
+    import torch
+    words = pkg.scenes.random_tree(seed=5, max_depth=9, p_split=0.55, p_solid=0.25, max_words=1 << 20)
+    rng = np.random.default_rng(77)
+    tiny = np.array([0.0, 1e-12, -1e-12, 1e-30, -1e-30, 1e-40, -1e-40, 1e-7, -1e-7, 2.0 ** -24, -(2.0 ** -24)], dtype=np.float32)
+    n = 30000
+    org = rng.uniform(-0.9, 0.9, (n, 3)).astype(np.float32)
+    for axis in range(3):
+        sel = rng.random(n) < 0.5
+        org[sel, axis] = tiny[rng.integers(0, tiny.size, int(sel.sum()))]
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::7, 0] = 0.0  # exercises the 1e-6 bias of zero direction components next to tiny origins (shader.wgsl:193-194)
+    rays = np.concatenate([org, d], axis=1).astype(np.float32)
+    gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+    for tree in (words, monu9_words):
+        render = pkg.Render(gpu, (8, 8), tree, capacity=tree.size)
+        for flags in (O.F_PAUSE_ADAPTIVE, O.F_PAUSE_ADAPTIVE | O.F_MISC_BOOL):
+            render.uniforms.flags = flags
+            render.upload_uniforms()
+            got = pkg.render.hits_to_numpy(render.trace_rays(torch.from_numpy(rays).cuda()))
+            gpu.sync()
+            assert_hits_equal(got, O.trace_rays(tree, rays, flags=flags, threads=8), f"tiny origins flags={flags}")
+    for pos, look in (((0.0, 0.0, -0.2), (0.3, 0.1, 1.0)), ((0.0, 0.25, 0.0), (1.0, -0.2, 0.4))):
+        u = O.make_uniforms(pos=pos, look=look, width=320, height=180, flags=O.F_PAUSE_ADAPTIVE)
+        assert_hits_equal(_render(pkg, gpu, words, u, variant), O.trace_frame(words, u, threads=8), f"camera on a centre plane {pos}")
