@@ -358,16 +358,15 @@ __device__ __forceinline__ ItemFast decode_item_fast(const WorkDesc &w, uint32_t
     return it;
 }
 
-// a / d given y = RN(1 / d): q0 = a*y is within 2 ulp of a/d; with the exact residuals r = a - d*q (fma)
-// each q + r*y correction squares the error, and by Markstein's theorem (y correctly rounded, q faithful)
-// the second correction returns the correctly rounded quotient -- the same bits as IEEE a / d.  Valid while
-// nothing over/underflows: the caller guarantees 2^-40 <= |d| <= 2^40 and a == 0 or 2^-53 <= |a| <= 2^21
-// (tools/divtest.c checks the sequence against a / d over those ranges).
+// a / d given y = RN(1 / d):  q0 = a*y,  r = a - d*q0 (exact, one fma),  q0 + r*y rounded once -- the same bits as
+// IEEE a / d.  Markstein's theorem gives this for a faithful q0; that q0 = RN(a*y) is always good enough is
+// established exhaustively: tools/divtest_gpu.hip compares the sequence with a / d for all 2^23 x 2^23 pairs
+// of significands (0 mismatches, profiles/r01_divtest_gpu.log; the uncorrected product fails on 27 %).  The
+// sequence is invariant under power-of-two scaling and sign changes while nothing over/underflows: the caller
+// guarantees 2^-17 <= |d| <= 2^63 and a == 0 or 2^-26 <= |a| <= 2^26 (grid units), so q0 and r stay normal.
 __device__ __forceinline__ float div_by_recip(float a, float d, float y) {
-    float q = a * y;
-    float r = __builtin_fmaf(-d, q, a);
-    q = __builtin_fmaf(r, y, q);
-    r = __builtin_fmaf(-d, q, a);
+    const float q = a * y;
+    const float r = __builtin_fmaf(-d, q, a);
     return __builtin_fmaf(r, y, q);
 }
 
