@@ -370,6 +370,18 @@ __device__ __forceinline__ float div_by_recip(float a, float d, float y) {
     return __builtin_fmaf(r, y, q);
 }
 
+// floor(x) and floor(-x) = -ceil(x) as integers in one instruction (|x| < 2^24 here, no saturation involved)
+__device__ __forceinline__ int32_t cvt_floor_i32(float x) {
+    int32_t r;
+    asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ int32_t cvt_floor_neg_i32(float x) {
+    int32_t r;
+    asm("v_cvt_flr_i32_f32_e64 %0, -%1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 __device__ __forceinline__ float copysign_bits(float mag, float sgn) {
     return __uint_as_float((__float_as_uint(mag) & 0x7FFFFFFFu) | (__float_as_uint(sgn) & 0x80000000u));
 }
@@ -720,13 +732,14 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
                 // new path codes: the position is inside the cube, so no clamping of G
                 int32_t jx, jy, jz;
                 if (GE) {
-                    jx = (int32_t)floorf(G0) + 8388608;
-                    jy = (int32_t)floorf(G1) + 8388608;
-                    jz = (int32_t)floorf(G2) + 8388608;
+                    jx = cvt_floor_i32(G0) + 8388608;
+                    jy = cvt_floor_i32(G1) + 8388608;
+                    jz = cvt_floor_i32(G2) + 8388608;
                 } else {
-                    jx = max((int32_t)ceilf(G0) + 8388607, 0);
-                    jy = max((int32_t)ceilf(G1) + 8388607, 0);
-                    jz = max((int32_t)ceilf(G2) + 8388607, 0);
+                    // ceil(G) - 1 + 2^23 clamped at 0, with ceil(G) = -floor(-G): the clamp only acts on the face G = -2^23
+                    jx = 8388607 - min(cvt_floor_neg_i32(G0), 8388607);
+                    jy = 8388607 - min(cvt_floor_neg_i32(G1), 8388607);
+                    jz = 8388607 - min(cvt_floor_neg_i32(G2), 8388607);
                 }
                 const uint32_t diff = (uint32_t)((ix ^ jx) | (iy ^ jy) | (iz ^ jz));
                 // levels shared by the old and new path: clz over the 24-bit codes (diff == 0: all 24)
