@@ -454,12 +454,14 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
     // (LPT scheduling: a ray is a serial chain of up to 101 rounds, so the long ones must start early or the
     // whole chip waits for them at the end); layout and rationale at strip_order_kernel.
     const uint32_t *order = a.order;  // 8 list lengths, then 8 lists of a.order_cap strip numbers
-    uint32_t strip = wave_id, shard_try = 0, next, strip_end;
-    auto claim = [&]() {
+    // (the cursor travels by value: captured by reference it stayed in scratch memory, and a load from scratch
+    // makes everything that depends on it -- the whole refill control flow -- divergent for the compiler)
+    struct Cursor { uint32_t next, end, strip, shard_try; };
+    auto claim = [=](Cursor c) -> Cursor {
         uint32_t s = 0xFFFFFFFFu;
         if (work_counter) {
-            while (shard_try < kShards) {
-                const uint32_t sh = (blockIdx.x + shard_try) % kShards;
+            while (c.shard_try < kShards) {
+                const uint32_t sh = (blockIdx.x + c.shard_try) % kShards;
                 uint32_t k = 0;
                 if (lane == 0) k = atomicAdd(work_counter + sh * kShardStride, 1u);
                 k = __builtin_amdgcn_readfirstlane(k);
@@ -469,21 +471,23 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
                     const uint32_t cand = sh * per_shard + k;
                     if (k < per_shard && cand < n_strips) { s = cand; break; }
                 }
-                shard_try += 1;
+                c.shard_try += 1;
             }
         } else {
-            if (strip < n_strips) s = strip;
-            strip += n_waves;
+            if (c.strip < n_strips) s = c.strip;
+            c.strip += n_waves;
         }
         if (s != 0xFFFFFFFFu) {
             s = __builtin_amdgcn_readfirstlane(s);
-            next = s * strip_items;
-            strip_end = min(next + strip_items, n_items);
+            c.next = s * strip_items;
+            c.end = min(c.next + strip_items, n_items);
         } else {
-            next = strip_end = 0xFFFFFFFFu;
+            c.next = c.end = 0xFFFFFFFFu;
         }
+        return c;
     };
-    claim();
+    Cursor cur = claim(Cursor{0u, 0u, wave_id, 0u});
+    uint32_t next = cur.next, strip_end = cur.end;
     uint32_t pool_n = 0, pool_i = 0;  // wave-uniform: rays waiting in the pool, index of the first
     // optional per-wave timeline (diagnostic builds of the host set a.debug): start, queue-dry, end in 10 ns ticks
     uint64_t t_begin = 0, t_dry = 0;
@@ -601,7 +605,11 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
                     pool_n = (uint32_t)__popcll(am);
                     pool_i = 0u;
                     next += min(64u, strip_end - next);
-                    if (next >= strip_end) claim();
+                    if (next >= strip_end) {
+                        cur = claim(cur);
+                        next = cur.next;
+                        strip_end = cur.end;
+                    }
                     if (a.debug && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
                 }
                 // -- idle lanes first write the record of the ray they finished, then take rays pool_i .. --
