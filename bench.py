@@ -49,9 +49,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: validation mode for boxes with fewer GPUs than ranks -- ranks share the visible GPUs and "
                          "the gather is staged through host memory (not a performance configuration)")
-    ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2],
-                    help="N=1 only: 2 = consecutive frames alternate between two HIP streams (the drain of one frame "
-                         "overlaps the next); the default 1 keeps frames serial, which is what roofline.* describes")
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="consecutive frames rotate over this many HIP streams / device contexts, so the serial tail of one "
+                         "frame's rays overlaps the next frames.  0 = default: 1 at N=1 (frames serial, which is what "
+                         "roofline.* describes), 3 at N>1 (a rank's share of a sharded frame is too small to fill a GPU)")
     ap.add_argument("--cpu-frac", type=int, default=1, help="cpu_baseline traces the top 1/n of the frame's rows")
     a = ap.parse_args()
 
@@ -99,19 +100,25 @@ def main():
 
     tw, th = a.tile_w, a.tile_h
     n_rays = W * H
-    if world == 1 and a.frames_in_flight == 2:
-        s2 = torch.cuda.Stream()
-        gpu2 = pkg.Gpu(local_rank, stream=s2.cuda_stream)
-        render2 = pkg.Render.share_nodes(gpu2, render)
-        gpu2.set_option(pkg.gpu.OPT_TIMING, max(a.steps, 1))
-        lanes = [(render, render.alloc_hits(n_rays), torch.cuda.current_stream()), (render2, render2.alloc_hits(n_rays), s2)]
+    if a.frames_in_flight == 0:
+        a.frames_in_flight = 1 if (world == 1 or a.backend == "gloo") else 3
+    # lane 0 = the context above on torch's current stream; further lanes: own HIP stream + context, same node buffer
+    lanes = [(gpu, render, torch.cuda.current_stream())]
+    for _ in range(a.frames_in_flight - 1):
+        s_k = torch.cuda.Stream()
+        gpu_k = pkg.Gpu(local_rank, stream=s_k.cuda_stream)
+        render_k = pkg.Render.share_nodes(gpu_k, render)
+        gpu_k.set_option(pkg.gpu.OPT_TIMING, max(a.steps, 1))
+        lanes.append((gpu_k, render_k, s_k))
+    if world == 1 and len(lanes) > 1:
+        bufs = [r.alloc_hits(n_rays) for _, r, _ in lanes]
         counter = [0]
 
         def step():
-            r, h, st = lanes[counter[0] & 1]
+            k = counter[0] % len(lanes)
             counter[0] += 1
-            r.render(hits=h)
-            return h
+            lanes[k][1].render(hits=bufs[k])
+            return bufs[k]
     elif world == 1:
         hits = render.alloc_hits(n_rays)
 
@@ -122,17 +129,22 @@ def main():
         assert W % tw == 0 and H % th == 0
         # frame i's RCCL gather overlaps frame i+1's trace (double-buffered); rank 0 un-permutes each frame
         if a.backend == "nccl":
-            pipe = pkg.sharding.FramePipeline(lambda buf: render.render_tiles(tw, th, rank, world, hits=buf),
-                                              W, H, tw, th, rank, world, f"cuda:{local_rank}")
+            traces = [(lambda buf, r=r: r.render_tiles(tw, th, rank, world, hits=buf)) for _, r, _ in lanes]
+            pipe = pkg.sharding.FramePipeline(traces, W, H, tw, th, rank, world, f"cuda:{local_rank}",
+                                              streams=[s for _, _, s in lanes])
         else:
             n_pad_v = pkg.sharding.padded_tile_count(W, H, tw, th, world)
-            dev_buf = torch.zeros((n_pad_v, th * tw, 4), dtype=torch.int32, device=f"cuda:{local_rank}")
 
-            def trace_via_host(buf):
-                render.render_tiles(tw, th, rank, world, hits=dev_buf)
-                buf.copy_(dev_buf)  # blocking D2H: validation only
+            def via_host(r):
+                dev_buf = torch.zeros((n_pad_v, th * tw, 4), dtype=torch.int32, device=f"cuda:{local_rank}")
 
-            pipe = pkg.sharding.FramePipeline(trace_via_host, W, H, tw, th, rank, world, "cpu")
+                def trace(buf):
+                    r.render_tiles(tw, th, rank, world, hits=dev_buf)
+                    buf.copy_(dev_buf)  # blocking D2H on the lane's stream: validation only
+                return trace
+
+            pipe = pkg.sharding.FramePipeline([via_host(r) for _, r, _ in lanes], W, H, tw, th, rank, world, "cpu",
+                                              streams=[s for _, _, s in lanes])
         step = pipe.step
 
     def barrier():
@@ -146,9 +158,8 @@ def main():
     if world > 1:
         pipe.drain()
     barrier()
-    gpu.timing_collect()  # drop the warm-up launches' records
-    if world == 1 and a.frames_in_flight == 2:
-        gpu2.timing_collect()
+    for g, _, _ in lanes:
+        g.timing_collect()  # drop the warm-up launches' records
     t_start = time.perf_counter()
     for _ in range(a.steps):
         out = step()
@@ -158,9 +169,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     # per-launch kernel durations of exactly the K timed launches: HIP event pairs recorded by the C ABI
     # around each launch on the launch stream
-    kms = gpu.timing_collect()
-    if world == 1 and a.frames_in_flight == 2:
-        kms = np.concatenate([kms, gpu2.timing_collect()])
+    kms = np.concatenate([g.timing_collect() for g, _, _ in lanes])
     assert len(kms) == a.steps
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if a.backend == "nccl" else "cpu")
@@ -182,7 +191,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
             "config": {"workload": a.workload, "width": W, "height": H, "octree_max_depth": wl["max_depth"],
                        "node_words": int(words.size), "node_bytes": int(words.size) * 4, "rays_per_step": n_rays,
-                       "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight, "backend": a.backend if world > 1 else None, "sharding": "none" if world == 1 else f"tiles {tw}x{th} round-robin, 1 RCCL gather per frame overlapped with the next frame's trace",
+                       "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight, "backend": a.backend if world > 1 else None, "sharding": "none" if world == 1 else f"tiles {tw}x{th} round-robin, 1 RCCL gather per frame overlapped with the following frames' traces",
                        "scene_gen_s": round(gen_s, 1)},
         }
         cpu = None

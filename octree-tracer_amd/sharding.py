@@ -6,6 +6,8 @@ holds a full replica of the node array.  The only data-path exchange is ONE gath
 to rank 0 at frame end (torch.distributed: RCCL over xGMI on the GPU box, gloo in CPU tests),
 after which rank 0 un-permutes tiles into the row-major frame.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -44,23 +46,41 @@ def assemble_frame(gathered, width, height, tile_w, tile_h):
 
 
 class FramePipeline:
-    """Double-buffered frame loop for N > 1 ranks: frame i's gather (RCCL, asynchronous) overlaps frame
-    i+1's trace; rank 0 assembles a frame once its gather has completed.  `trace(buf)` must enqueue the
-    rank's tiles into `buf` ([n_pad, tile_h * tile_w, 4] int32) on the current stream.
+    """Pipelined frame loop for N > 1 ranks: frame i's gather (RCCL, asynchronous) overlaps the trace of the
+    following frames; rank 0 assembles a frame once its gather has completed.
+
+    `trace` is a callable `trace(buf)` that enqueues the rank's tiles into `buf` ([n_pad, tile_h * tile_w, 4]
+    int32) on the current stream -- or a list of such callables, one per LANE, together with `streams` (one
+    torch.cuda.Stream per lane): consecutive frames then go to different HIP streams (each lane drives its own
+    device context), so the serial tail of one frame's rays overlaps the next frames.  A rank's share of a
+    sharded frame is small, and a ray is a serial chain of up to 101 dependent rounds: with one frame at a
+    time the GPU idles through every frame's tail (tools/pipeline_probe.py: 1/8 of a 1080p frame takes 0.18 ms
+    alone and 0.085 ms with three frames in flight).
 
     step() returns the most recent COMPLETED frame on rank 0 (None until the first one is ready, and on
     other ranks); drain() completes what is in flight and returns the last frame."""
 
-    def __init__(self, trace, width, height, tile_w, tile_h, rank, world, device, group=None):
-        self.trace, self.rank, self.world, self.group = trace, rank, world, group
+    def __init__(self, trace, width, height, tile_w, tile_h, rank, world, device, group=None, streams=None):
+        self.traces = list(trace) if isinstance(trace, (list, tuple)) else [trace]
+        self.streams = list(streams) if streams is not None else None
+        if self.streams is not None and len(self.streams) != len(self.traces):
+            raise ValueError("one stream per lane")
+        self.rank, self.world, self.group = rank, world, group
         self.dims = (width, height, tile_w, tile_h)
+        self.n_buf = max(2, len(self.traces))  # a lone lane is still double-buffered against its gather
         n_pad = padded_tile_count(width, height, tile_w, tile_h, world)
-        self.local = [torch.zeros((n_pad, tile_h * tile_w, 4), dtype=torch.int32, device=device) for _ in range(2)]
+        self.local = [torch.zeros((n_pad, tile_h * tile_w, 4), dtype=torch.int32, device=device) for _ in range(self.n_buf)]
         self.gathered = [torch.empty((world, n_pad, tile_h * tile_w, 4), dtype=torch.int32, device=device)
-                         if rank == 0 else None for _ in range(2)]
-        self.work = [None, None]
+                         if rank == 0 else None for _ in range(self.n_buf)]
+        self.work = [None] * self.n_buf
         self.frame = None
         self.i = 0
+
+    def _on_lane(self, b):
+        """context: the stream of the lane that owns buffer b"""
+        if self.streams is None:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(self.streams[b % len(self.traces)])
 
     def _finish(self, b):
         if self.work[b] is not None:
@@ -70,18 +90,24 @@ class FramePipeline:
                 self.frame = assemble_frame(self.gathered[b], *self.dims).contiguous()
 
     def step(self):
-        b = self.i & 1
-        self._finish(b)          # buffer b is free again once frame i-2 has been gathered
-        self.trace(self.local[b])
-        if self.rank == 0:
-            self.work[b] = dist.gather(self.local[b], list(self.gathered[b].unbind(0)), dst=0, group=self.group,
-                                       async_op=True)
-        else:
-            self.work[b] = dist.gather(self.local[b], None, dst=0, group=self.group, async_op=True)
+        b = self.i % self.n_buf
+        with self._on_lane(b):
+            self._finish(b)      # buffer b is free again once the frame that used it has been gathered
+            self.traces[b % len(self.traces)](self.local[b])
+            if self.rank == 0:
+                self.work[b] = dist.gather(self.local[b], list(self.gathered[b].unbind(0)), dst=0, group=self.group,
+                                           async_op=True)
+            else:
+                self.work[b] = dist.gather(self.local[b], None, dst=0, group=self.group, async_op=True)
         self.i += 1
         return self.frame
 
     def drain(self):
-        self._finish(self.i & 1)
-        self._finish((self.i + 1) & 1)
+        for k in range(self.n_buf):  # oldest frame first, so that self.frame ends up as the newest
+            b = (self.i + k) % self.n_buf
+            with self._on_lane(b):
+                self._finish(b)
+        if self.streams is not None:
+            for st in self.streams:
+                st.synchronize()
         return self.frame

@@ -65,6 +65,28 @@ def _worker(rank, world, port, W, H, tw, th, out_path):
         if rank == 0:
             got = last.numpy().view(np.uint32)
             ok = ok and bool(np.array_equal(got, want + np.uint32(3)))
+        # three lanes (bench.py's default for N > 1: consecutive frames on different streams / contexts; no
+        # streams on the CPU): 7 frames rotate over 3 buffers, each lane sees every third frame, in order
+        seen = [[], [], []]
+        count = [0]
+
+        def lane_trace(lane):
+            def trace(buf):
+                count[0] += 1
+                seen[lane].append(count[0])
+                buf.copy_(local + 100 * count[0])
+            return trace
+
+        pipe = sh.FramePipeline([lane_trace(k) for k in range(3)], W, H, tw, th, rank, world, "cpu")
+        done = [pipe.step() for k in range(7)]
+        last = pipe.drain()
+        ok = ok and seen == [[1, 4, 7], [2, 5], [3, 6]]
+        if rank == 0:
+            # step k (0-based) first frees its buffer: the frame that used it, k - 3, is complete by then
+            for k in range(3, 7):
+                ok = ok and bool(np.array_equal(done[k].numpy().view(np.uint32), want + np.uint32(100 * (k - 2))))
+            ok = ok and done[2] is None
+            ok = ok and bool(np.array_equal(last.numpy().view(np.uint32), want + np.uint32(700)))
             np.save(out_path, np.array([int(ok)]))
     finally:
         dist.destroy_process_group()
