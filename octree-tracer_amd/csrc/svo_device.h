@@ -58,7 +58,7 @@ struct LaunchInfo {
     int variant;
     int grid_blocks;         // 0 = auto
     int num_cus;
-    bool deep_stack;         // STACK: 19-level ancestor stack (trees deeper than 18 levels)
+    bool deep_stack;         // STACK: 19-level ancestor stack (trees deeper than 16 levels)
     uint32_t strip_items;    // STACK: pixel slots a wave claims at a time (multiple of 64)
     uint32_t *counters;      // STACK: kCounterWords claim-counter words, zero when a frame starts
     uint32_t *work_counter;  // STACK: counters + 0 for dynamic strip claiming, or nullptr (static round-robin)

@@ -382,6 +382,13 @@ __device__ __forceinline__ int32_t cvt_floor_neg_i32(float x) {
     return r;
 }
 
+// path code of a finite position given in grid units (|g| <= 2^24), clamped into the cube like path_code()
+template <bool GE>
+__device__ __forceinline__ int32_t entry_code(float g) {
+    const int32_t i = GE ? cvt_floor_i32(g) + 8388608 : 8388607 - cvt_floor_neg_i32(g);
+    return min(max(i, 0), 0x00FFFFFF);
+}
+
 __device__ __forceinline__ float copysign_bits(float mag, float sgn) {
     return __uint_as_float((__float_as_uint(mag) & 0x7FFFFFFFu) | (__float_as_uint(sgn) & 0x80000000u));
 }
@@ -406,17 +413,18 @@ constexpr uint32_t ST_L_MASK = 31u << ST_L_SHIFT, ST_M_MASK = 7u << ST_M_SHIFT;
 // Ray pool: a wave generates the rays of up to 64 work items at once, with every lane busy (lanes that
 // are still traversing compute a ray for somebody else), compacts the ones that enter the cube into LDS,
 // and idle lanes later pick them up.  Ray generation and set-up (2 mat-vecs, 14 IEEE divisions, a square
-// root, the entry path codes) are thereby paid once per 64 rays at full lane utilisation instead of on
+// root) are thereby paid once per 64 rays at full lane utilisation instead of on
 // every refill.  Pool record: P.xyz, Dr.xyz, Y.xyz (position, biased direction and its reciprocal, all in
-// grid units, see below), dist, out | entry normal code << 26, path codes x, y, z.
-constexpr int kPoolWords = 14;
+// grid units, see below), dist, out | entry normal code << 26.  (The entry path codes are recomputed at pick-up:
+// 11 words per ray keep a workgroup at 26 KiB of LDS, i.e. 6 workgroups per CU.)
+constexpr int kPoolWords = 11;
 
 // The traversal runs in GRID UNITS: positions and directions are pre-multiplied by 2^23 (the path-code
 // scale).  Scaling by a power of two commutes with every IEEE rounding involved (no overflow/underflow on
 // a clean ray), so  A = (C - P) + H,  t = A / Dr,  G = (P + Dr * t) +- K  are exactly 2^23 times the
 // reference's  a,  the same t,  and  2^23 * voxel_pos  -- and G is what the path codes need.
 template <int BLOCK, int NS, int K, bool GE>
-__global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
+__global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
@@ -598,9 +606,6 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
                         pool[8 * 64 + slot] = __float_as_uint(1.0f / gd2);
                         pool[9 * 64 + slot] = __float_as_uint(gdist);
                         pool[10 * 64 + slot] = gout;
-                        pool[11 * 64 + slot] = (uint32_t)path_code(gp0, GE);
-                        pool[12 * 64 + slot] = (uint32_t)path_code(gp1, GE);
-                        pool[13 * 64 + slot] = (uint32_t)path_code(gp2, GE);
                     }
                     pool_n = (uint32_t)__popcll(am);
                     pool_i = 0u;
@@ -634,9 +639,10 @@ __global__ __launch_bounds__(BLOCK, 5) void trace_stack_kernel(TraceArgs a, uint
                         K2 = copysign_bits(0.000002f * 8388608.0f, Dr2);
                         dist = __uint_as_float(pool[9 * 64 + e]);
                         out = pool[10 * 64 + e];
-                        ix = (int32_t)pool[11 * 64 + e];
-                        iy = (int32_t)pool[12 * 64 + e];
-                        iz = (int32_t)pool[13 * 64 + e];
+                        // entry path codes (the position may sit a rounding error outside the cube: clamp)
+                        ix = entry_code<GE>(P0);
+                        iy = entry_code<GE>(P1);
+                        iz = entry_code<GE>(P2);
                         tcur = 0.0f;
                         st = ST_ACTIVE | ST_DESC | ST_ENTRY;  // steps = 0, L = 0
                         restart_at(1u);
@@ -1102,9 +1108,9 @@ hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint3
 }
 
 constexpr int kStackBlock = 256;
-constexpr int kStackLevels = 14;      // default: resolves levels up to 3 + 1 + 14 = 18
+constexpr int kStackLevels = 12;      // default: resolves levels up to 3 + 1 + 12 = 16
 constexpr int kStackLevelsDeep = 19;  // deep trees: up to level 23
-constexpr int kPoolWordsHost = 14;
+constexpr int kPoolWordsHost = 11;
 
 int stack_max_depth(bool deep) { return kTopLevels + 1 + (deep ? kStackLevelsDeep : kStackLevels); }
 

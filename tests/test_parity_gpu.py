@@ -482,7 +482,7 @@ def test_config5_fractal_depth20(pkg, gpu, O):
     set_uniforms_from_oracle(render, u)
     gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
     try:
-        # default kernel resolves 18 levels: it must refuse loudly, not return wrong voxels
+        # default kernel resolves 16 levels: it must refuse loudly, not return wrong voxels
         render.render()
         with pytest.raises(pkg.SvoError):
             gpu.sync()
