@@ -37,7 +37,7 @@ struct svo_ctx {
     // options
     int variant = SVO_VARIANT_STACK;
     int grid_blocks = 0;
-    uint32_t refill_min = 8;
+    uint32_t refill_min = 12;
     uint32_t prio_steps = 0;
     uint32_t block_w_log2 = 3;  // 64-pixel blocks of 8x8
     uint32_t tree_depth = 16;  // caller's bound on the octree depth (the reference's Settings.octree_depth)
