@@ -546,11 +546,15 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
 
     for (;;) {
         // ---- 1. refill idle lanes from the ray pool (ballot compaction) ----
+        // Common case first and cheap: fewer than refill_min idle lanes -> straight on.  (refill_min <= 64, so a wave
+        // without active lanes always takes the slow path, where the exit test lives.)
         uint64_t act = __ballot((st & ST_ACTIVE) != 0u);
-        const bool more = (pool_n != 0u) || (next != 0xFFFFFFFFu);
-        if (more) {
-            uint32_t n_idle = 64u - (uint32_t)__popcll(act);
-            if (n_idle >= a.refill_min || act == 0ull) {
+        const uint32_t n_idle = 64u - (uint32_t)__popcll(act);
+        if (n_idle >= a.refill_min) {
+            const bool more = (pool_n != 0u) || (next != 0xFFFFFFFFu);
+            if (!more) {
+                if (act == 0ull) break;
+            } else {
                 if (a.debug) dbg_refills += 1;
                 if (pool_n == 0u) {
                     if (a.debug) dbg_gens += 1;
@@ -657,8 +661,6 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                     continue;
                 }
             }
-        } else if (act == 0ull) {
-            break;
         }
 
         n_rounds += 1;
