@@ -97,7 +97,8 @@ typedef enum svo_option {
                                 <= 16: default kernel; <= 23: deep-stack kernel; above: the general RESTART kernel */
     SVO_OPT_BLOCK_SHAPE = 10, /* log2 of the width of the 64-pixel blocks a wave works on (3: 8x8, 4: 16x4, ...) */
     SVO_OPT_DEBUG_BUFFER = 7, /* device pointer receiving 8 words per wave: start, queue-dry, end (10 ns ticks), rounds, ... */
-    SVO_OPT_PRIO_STEPS = 6   /* waves carrying rays with >= this many steps raise their issue priority (0 = off) */
+    SVO_OPT_PRIO_STEPS = 6   /* accepted and ignored: raising the issue priority of waves with old rays measured no effect and
+                                left the kernel */
 } svo_option;
 
 int svo_ctx_create(int hip_device, svo_ctx **out);

@@ -127,7 +127,6 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     a.aux_t = opt.aux_t;
     a.status = ctx->status;
     a.refill_min = ctx->refill_min;
-    a.prio_steps = ctx->prio_steps;
     a.debug = ctx->debug_buf;
     // shader.wgsl:159: counters are live unless pause_adaptive; rays handed in by the caller (svo_trace_rays) never count
     const bool counting = (work.mode != 2 || opt.count_rays) && !(ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE);

@@ -51,7 +51,6 @@ struct TraceArgs {
     const uint32_t *order;      // STACK, optional: schedule built by strip_order_kernel (8 lengths + 8 lists)
     uint32_t order_cap;         // entries reserved per list
     uint32_t *debug;            // optional: 8 words per wave (start, queue-dry, end ticks of 10 ns, rounds, active-lane sum, ...)
-    uint32_t prio_steps;        // STACK: waves carrying rays with at least this many steps raise their priority (0 = off)
 };
 
 struct LaunchInfo {

@@ -423,7 +423,7 @@ constexpr int kPoolWords = 11;
 // scale).  Scaling by a power of two commutes with every IEEE rounding involved (no overflow/underflow on
 // a clean ray), so  A = (C - P) + H,  t = A / Dr,  G = (P + Dr * t) +- K  are exactly 2^23 times the
 // reference's  a,  the same t,  and  2^23 * voxel_pos  -- and G is what the path codes need.
-template <int BLOCK, int NS, int K, bool GE>
+template <int BLOCK, int NS, int K, bool GE, bool DBG>
 __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
     // optional per-wave timeline (diagnostic builds of the host set a.debug): start, queue-dry, end in 10 ns ticks
     uint64_t t_begin = 0, t_dry = 0;
     uint32_t n_rounds = 0, dbg_active = 0, dbg_iters = 0, dbg_refills = 0, dbg_gens = 0;
-    if (a.debug) t_begin = __builtin_amdgcn_s_memrealtime();
+    if (DBG) t_begin = __builtin_amdgcn_s_memrealtime();
 
     // per-lane ray state
     uint32_t st = 0;                  // packed, see ST_*
@@ -555,9 +555,9 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
             if (!more) {
                 if (act == 0ull) break;
             } else {
-                if (a.debug) dbg_refills += 1;
+                if (DBG) dbg_refills += 1;
                 if (pool_n == 0u) {
-                    if (a.debug) dbg_gens += 1;
+                    if (DBG) dbg_gens += 1;
                     // -- generate the next (up to) 64 rays, all lanes --
                     const uint32_t q = next + lane;
                     bool alive = false;
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                         next = cur.next;
                         strip_end = cur.end;
                     }
-                    if (a.debug && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
+                    if (DBG && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
                 }
                 // -- idle lanes first write the record of the ray they finished, then take rays pool_i .. --
                 if (st & ST_PENDING) flush_record();
@@ -663,15 +663,9 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
             }
         }
 
-        n_rounds += 1;
-        if (a.debug) dbg_active += (uint32_t)__popcll(__ballot((st & ST_ACTIVE) != 0u));
-        // Old rays decide when the kernel ends (a ray is a serial chain of up to 101 dependent rounds, and the
-        // last ones drain after the work queue is empty): waves that carry rays past a.prio_steps steps get
-        // issue priority over the waves they share a SIMD with.  (Measured: no effect on the benchmark -- in the
-        // drain every wave carries old rays -- so it is off by default.)
-        if (a.prio_steps != 0u) {
-            const bool old_rays = __ballot((st & ST_ACTIVE) && ((st & 0xFFu) >= a.prio_steps)) != 0ull;
-            if (old_rays) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        if (DBG) {  // per-wave timeline build only (SVO_OPT_DEBUG_BUFFER): the default instantiation carries none of this
+            n_rounds += 1;
+            dbg_active += (uint32_t)__popcll(__ballot((st & ST_ACTIVE) != 0u));
         }
 
         // ---- 2. descent: one dependent word per level below the restart level ----
@@ -767,7 +761,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
         }
     }
     if (st & ST_PENDING) flush_record();
-    if (a.debug && lane == 0) {
+    if (DBG && lane == 0) {
         uint64_t t_end = __builtin_amdgcn_s_memrealtime();
         uint32_t *d = a.debug + 8u * wave_id;
         d[0] = (uint32_t)t_begin;
@@ -1119,7 +1113,7 @@ int stack_max_depth(bool deep) { return kTopLevels + 1 + (deep ? kStackLevelsDee
 template <bool GE, int NS>
 static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
     const uint32_t strip_items = args.order ? 64u : (li.strip_items ? li.strip_items : 64u);
-    auto kern = trace_stack_kernel<kStackBlock, NS, kTopLevels, GE>;
+    auto kern = args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true> : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false>;
     size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64) *
                        sizeof(uint32_t);
     static int blocks_per_cu = 0;
