@@ -403,9 +403,9 @@ __device__ __forceinline__ bool clean_component(float p, float d) {
 }
 
 // Per-lane state word: bits 0..7 steps | 8..12 leaf depth L | 13..15 step mask (axes of the last step's
-// normal) | 16 normal-is-entry-normal | 19 active | 20 needs descent | 21 record pending | 22..24 how it ended
+// normal) | 16 normal-is-entry-normal | 31 active | 30 needs descent (only ever set together with active) | 21 record pending | 22..24 how it ended
 constexpr uint32_t ST_L_SHIFT = 8, ST_M_SHIFT = 13;
-constexpr uint32_t ST_ENTRY = 1u << 16, ST_ACTIVE = 1u << 19, ST_DESC = 1u << 20;
+constexpr uint32_t ST_ENTRY = 1u << 16, ST_ACTIVE = 1u << 31, ST_DESC = 1u << 30;
 // a finished ray keeps its state until the lane is refilled: record not yet written + how it ended
 constexpr uint32_t ST_PENDING = 1u << 21, ST_F_TOODEEP = 1u << 22, ST_F_SOLID = 1u << 23, ST_F_INB = 1u << 24;
 constexpr uint32_t ST_L_MASK = 31u << ST_L_SHIFT, ST_M_MASK = 7u << ST_M_SHIFT;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
     float dist = 0.0f, tcur = 0.0f;
     int32_t ix = 0, iy = 0, iz = 0;
     uint32_t lvl = 1, nidx = 0;       // next level to read and the child group it lives in
-    uint32_t leaf_p = 0, leaf_w = 0;  // current leaf: word index and word
+    uint32_t leaf_off = 0, leaf_w = 0;  // current leaf: byte offset of its word, and the word
 
     // (re)start a descent: from the LDS top table when the restart level r is at most K+1 (the table also
     // knows leaves that cover a whole level-K cell), else from the lane's ancestor stack.  One LDS read.
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
         uint32_t ncode = ((nm & 1u) ? c0n : 0u) | ((nm & 2u) ? (c1n << 2) : 0u) | ((nm & 4u) ? (c2n << 4) : 0u);
         if (st & ST_ENTRY) ncode = out >> 26;             // no step taken: the entry normal
         if (!stop_here && !inb) ncode = 0u;               // left the cube: the miss record carries no normal
-        const uint32_t value = too_deep ? 0xFF000000u : (solid ? leaf_p : (!inb ? 0x20202000u : 0xFF000000u));
+        const uint32_t value = too_deep ? 0xFF000000u : (solid ? (leaf_off >> 2) : (!inb ? 0x20202000u : 0xFF000000u));
         const uint32_t depth = (too_deep || (!solid && inb)) ? 100u : L;
         const uint32_t hit = (stop_here || inb) ? 1u : 0u;
         write_hit(a.hits, out & 0x03FFFFFFu, value, dist + tcur, st & 0xFFu, depth, hit, ncode);
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
         // ---- 1. refill idle lanes from the ray pool (ballot compaction) ----
         // Common case first and cheap: fewer than refill_min idle lanes -> straight on.  (refill_min <= 64, so a wave
         // without active lanes always takes the slow path, where the exit test lives.)
-        uint64_t act = __ballot((st & ST_ACTIVE) != 0u);
+        uint64_t act = __ballot((int32_t)st < 0);  // ST_ACTIVE is the sign bit: one compare
         const uint32_t n_idle = 64u - (uint32_t)__popcll(act);
         if (n_idle >= a.refill_min) {
             const bool more = (pool_n != 0u) || (next != 0xFFFFFFFFu);
@@ -669,38 +669,43 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
         }
 
         // ---- 2. descent: one dependent word per level below the restart level ----
-        if (st & ST_DESC) {
+        if (st >= (ST_ACTIVE | ST_DESC)) {  // DESC implies ACTIVE: one unsigned compare
             uint32_t off, w, key;
-            uint32_t sh = (uint32_t)D - lvl;                 // bit of the path codes that selects the child
-            uint32_t rem = (uint32_t)(SMAX - 1) - lvl;       // wraps below zero (sign bit) once level SMAX is reached
+            uint32_t sh = (uint32_t)D - lvl + 1u;            // (bit of the path codes that selects the child) + 1
             // slot of level lvl + 1; a descent that starts on a leaf above level K+1 (from the top table) pushes its
             // one dead word into row 0, which is rewritten before any restart can read it
             uint32_t sp = (uint32_t)TBL + (max(lvl, (uint32_t)(SBASE - 1)) - (uint32_t)(SBASE - 1)) * BLOCK + tid;
             // straight-line body, one exit test: the push also happens on the exiting iteration (it lands in the
             // slot below the leaf, which no restart reads; the stack has one spare row for an exit at level SMAX)
             do {
-                // child = x << 2 | y << 1 | z; byte offset = (nidx + child) << 2.  Three-operand forms the compiler does
-                // not pick by itself (single VALU instructions, no memory, no hazards)
-                uint32_t child = __builtin_amdgcn_ubfe((uint32_t)ix, sh, 1u);
-                asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(child) : "v"(child), "v"(__builtin_amdgcn_ubfe((uint32_t)iy, sh, 1u)));
-                asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(child) : "v"(child), "v"(__builtin_amdgcn_ubfe((uint32_t)iz, sh, 1u)));
-                asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(off) : "v"(nidx), "v"(child));
+                // sh -= 1 (level being read: D - sh); child = x << 2 | y << 1 | z; byte offset = (nidx + child) << 2.
+                // Three-operand forms the compiler does not pick by itself, in ONE asm statement (the compiler pads every
+                // inline-asm statement with an s_nop, and keeping the decrement inside saves a copy of the counter)
+                uint32_t tmp;
+                asm("v_add_u32 %2, -1, %2\n\t"
+                    "v_bfe_u32 %0, %3, %2, 1\n\t"
+                    "v_bfe_u32 %1, %4, %2, 1\n\t"
+                    "v_lshl_or_b32 %0, %0, 1, %1\n\t"
+                    "v_bfe_u32 %1, %5, %2, 1\n\t"
+                    "v_lshl_or_b32 %0, %0, 1, %1\n\t"
+                    "v_add_lshl_u32 %0, %6, %0, 2"
+                    : "=&v"(off), "=&v"(tmp), "+v"(sh)
+                    : "v"(ix), "v"(iy), "v"(iz), "v"(nidx));
                 w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
                 nidx = w >> 4;
                 lds[sp] = nidx;
                 sp += BLOCK;
-                key = w | rem;  // sign bit: a leaf (word >= VOXEL_OFFSET << 4) or level SMAX reached (deeper trees are refused)
-                sh -= 1u;
-                rem -= 1u;
+                // sign bit: a leaf (word >= VOXEL_OFFSET << 4), or level SMAX reached (deeper trees are refused)
+                key = w | (sh - (uint32_t)(D - SMAX + 1));
             } while ((int32_t)key >= 0);
-            lvl = (uint32_t)D - 1u - sh;
-            leaf_p = off >> 2;
+            lvl = (uint32_t)D - sh;
+            leaf_off = off;
             leaf_w = w;
             st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
         }
 
         // ---- 3. hit test / DDA step (shader.wgsl:215-244), clean rays, grid units ----
-        if (st & ST_ACTIVE) {
+        if ((int32_t)st < 0) {  // ST_ACTIVE
             const uint32_t L = (st >> ST_L_SHIFT) & 31u;
             const bool too_deep = leaf_w < (kVoxelOffset << 4);  // descent stopped on an interior word
             const bool solid = (leaf_w >> 4) != kVoxelOffset;
@@ -747,9 +752,15 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                     jz = cvt_floor_i32(G2) + 8388608;
                 } else {
                     // ceil(G) - 1 + 2^23 clamped at 0, with ceil(G) = -floor(-G): the clamp only acts on the face G = -2^23
-                    jx = 8388607 - min(cvt_floor_neg_i32(G0), 8388607);
-                    jy = 8388607 - min(cvt_floor_neg_i32(G1), 8388607);
-                    jz = 8388607 - min(cvt_floor_neg_i32(G2), 8388607);
+                    int32_t f0, f1, f2;  // floor(-G): one asm statement for the three conversions (see the descent)
+                    asm("v_cvt_flr_i32_f32_e64 %0, -%3\n\t"
+                        "v_cvt_flr_i32_f32_e64 %1, -%4\n\t"
+                        "v_cvt_flr_i32_f32_e64 %2, -%5"
+                        : "=&v"(f0), "=&v"(f1), "=&v"(f2)
+                        : "v"(G0), "v"(G1), "v"(G2));
+                    jx = 8388607 - min(f0, 8388607);
+                    jy = 8388607 - min(f1, 8388607);
+                    jz = 8388607 - min(f2, 8388607);
                 }
                 const uint32_t diff = (uint32_t)((ix ^ jx) | (iy ^ jy) | (iz ^ jz));
                 // levels shared by the old and new path: clz over the 24-bit codes (diff == 0: all 24)
