@@ -552,9 +552,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
         const uint32_t n_idle = 64u - (uint32_t)__popcll(act);
         if (n_idle >= a.refill_min) {
             const bool more = (pool_n != 0u) || (next != 0xFFFFFFFFu);
-            if (!more) {
-                if (act == 0ull) break;
-            } else {
+            if (more) {
                 if (DBG) dbg_refills += 1;
                 if (pool_n == 0u) {
                     if (DBG) dbg_gens += 1;
@@ -655,12 +653,11 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                 const uint32_t took = min(n_idle, pool_n);
                 pool_i += took;
                 pool_n -= took;
-                act = __ballot((st & ST_ACTIVE) != 0u);
-                if (act == 0ull) {
-                    if (pool_n == 0u && next == 0xFFFFFFFFu) break;
-                    continue;
-                }
+                act = __ballot((int32_t)st < 0);
             }
+            // the only exit: nothing in flight, nothing pooled, nothing left to claim.  (No lane active but work left --
+            // e.g. a strip whose rays all miss the cube: the traversal below is skipped lane-wise and the loop comes back.)
+            if (act == 0ull && pool_n == 0u && next == 0xFFFFFFFFu) break;
         }
 
         if (DBG) {  // per-wave timeline build only (SVO_OPT_DEBUG_BUFFER): the default instantiation carries none of this
