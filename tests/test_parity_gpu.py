@@ -16,11 +16,17 @@ def _render(pkg, gpu, words, u, variant, capacity=None, tile=None):
                         capacity=capacity or max(words.size, 64))
     set_uniforms_from_oracle(render, u)
     gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
-    first = pkg.render.hits_to_numpy(render.render(tile=tile))
+    n = int(u.dimensions[0]) * int(u.dimensions[1]) if tile is None else tile[2] * tile[3]
+    # output buffers are poisoned first: a ray that is dropped (never traced, record never written) must show
+    buf = render.alloc_hits(n)
+    buf.fill_(-1)
+    first = pkg.render.hits_to_numpy(render.render(hits=buf, tile=tile))
     gpu.sync()
     # the second frame of the same layout is scheduled from the first one's step counts (longest rays
     # first); the records must not depend on the schedule
-    hits = render.render(tile=tile)
+    buf2 = render.alloc_hits(n)
+    buf2.fill_(-1)
+    hits = render.render(hits=buf2, tile=tile)
     gpu.sync()
     second = pkg.render.hits_to_numpy(hits)
     assert np.array_equal(first.view(np.uint32), second.view(np.uint32)), "records depend on the strip schedule"
@@ -523,7 +529,9 @@ def test_bench_workload_full_size(pkg, gpu, O):
     gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
     frames = []
     for _ in range(3):
-        frames.append(pkg.render.hits_to_numpy(render.render()))
+        buf = render.alloc_hits(W * H)
+        buf.fill_(-1)  # poisoned: a dropped ray would keep it
+        frames.append(pkg.render.hits_to_numpy(render.render(hits=buf)))
         gpu.sync()
     assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
     assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))

@@ -37,8 +37,9 @@ print("drain us  ", np.percentile(end - dry, pct).round(1))
 print("rounds    ", np.percentile(d[:, 3], pct).round(0))
 print("us/round  ", np.percentile((end - start) / np.maximum(d[:, 3], 1), pct).round(2))
 print("active lanes per round (mean over waves):", (d[:, 4].sum() / d[:, 3].sum()).round(2), " refills/round", (d[:, 6].sum() / d[:, 3].sum()).round(3), " gens", int(d[:, 7].sum()), " total rounds", int(d[:, 3].sum()))
+print("steps of the last rays of a wave, by end-time decile:", [int(np.median(d[np.argsort(end)][i * len(d) // 10:(i + 1) * len(d) // 10, 5])) for i in range(10)])
 idx = np.argsort(end)[-8:]
-print("latest waves: id, dry, end, rounds")
+print("latest waves: id, dry, end, rounds, steps of its last ray")
 ids = np.flatnonzero(dbg.cpu().numpy().view(np.uint32)[:, 2] != 0)
 for i in idx:
-    print(int(ids[i]), round(float(dry[i]), 1), round(float(end[i]), 1), int(d[i, 3]))
+    print(int(ids[i]), round(float(dry[i]), 1), round(float(end[i]), 1), int(d[i, 3]), int(d[i, 5]))
