@@ -768,6 +768,12 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
             }
         }
     }
+    if (DBG) {  // the rays that finish last: their step counts tell whether the tail is long rays or late starts
+        uint32_t last = (st & ST_PENDING) ? (st & 0xFFu) : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) last = max(last, (uint32_t)__shfl_xor((int)last, o));
+        dbg_iters = last;
+    }
     if (st & ST_PENDING) flush_record();
     if (DBG && lane == 0) {
         uint64_t t_end = __builtin_amdgcn_s_memrealtime();
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
         d[2] = (uint32_t)t_end;
         d[3] = n_rounds;
         d[4] = dbg_active;   // sum over rounds of active lanes
-        d[5] = dbg_iters;    // (unused)
+        d[5] = dbg_iters;    // largest step count among the rays the wave finished last
         d[6] = dbg_refills;
         d[7] = dbg_gens;
     }
