@@ -45,6 +45,13 @@ __device__ __forceinline__ uint32_t load_word(rsrc_t rs, uint32_t idx) {
     return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(idx << 2), 0, 0);
 }
 
+// The same load with device scope (sc0 | sc1: past the per-CU vector cache, which is not coherent with atomics).  Used
+// when hit counters are live: a word that other rays have already driven to 15 must READ as 15, or every visit pays
+// a compare-and-swap that fails -- the hot top-level words would sit stale in every CU's L1 for the whole frame.
+__device__ __forceinline__ uint32_t load_word_device_scope(rsrc_t rs, uint32_t idx) {
+    return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(idx << 2), 0, 0x11);
+}
+
 struct RayIn {
     float px, py, pz, dx, dy, dz;
 };
@@ -173,13 +180,34 @@ __device__ __forceinline__ RayIn item_ray(const TraceArgs &a, const Item &it) {
 // n.data[p] = value + 1`.  The reference's plain read-modify-write races between rays; here the increment is a
 // compare-and-swap that stops at 15, so the counters after a frame are min(15, old + visits) whatever the
 // order (the oracle's oracle_count_frame).  Words saturate after 15 visits and are then only read.
-__device__ __forceinline__ void count_visit(uint32_t *nodes, uint32_t n_words, uint32_t p, uint32_t word) {
-    if (p >= n_words) return;
+__device__ __forceinline__ void count_add(uint32_t *nodes, uint32_t p, uint32_t word, uint32_t n) {
     while ((word & 15u) < 15u) {
-        const uint32_t seen = atomicCAS(&nodes[p], word, word + 1u);
+        const uint32_t seen = atomicCAS(&nodes[p], word, word + min(n, 15u - (word & 15u)));
         if (seen == word) break;
         word = seen;
     }
+}
+
+// Called by all lanes that are at the same level of their descent.  Rays of a wave are coherent: near the root all 64
+// lanes visit the same word, and 64 lanes racing their compare-and-swaps on one word cost 64 atomics per increment
+// (a 1080p frame took 400 ms that way).  Lanes with the same word are therefore grouped (ballot on the address of the
+// first lane still waiting) and one of them adds the size of the group; once groups are down to single lanes the
+// rest go individually (distinct addresses, no contention).
+__device__ __forceinline__ void count_visit(uint32_t *nodes, uint32_t n_words, uint32_t p, uint32_t word) {
+    bool need = p < n_words && (word & 15u) < 15u;
+    uint64_t todo = __ballot(need);
+    const uint32_t lane = __lane_id();
+    while (todo) {
+        const uint32_t leader = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)leader);
+        const uint64_t grp = __ballot(need && p == p0);
+        const uint32_t n = (uint32_t)__popcll(grp);
+        if (n == 1u) break;
+        if (lane == leader) count_add(nodes, p, word, n);
+        if (p == p0) need = false;
+        todo &= ~grp;
+    }
+    if (need) count_add(nodes, p, word, 1u);
 }
 
 __device__ __forceinline__ void trace_one_restart(const TraceArgs &a, rsrc_t rs, bool misc_bool, bool counter_hits,
@@ -214,8 +242,12 @@ __device__ __forceinline__ void trace_one_restart(const TraceArgs &a, rsrc_t rs,
             c1 = c1 + ((float)by * 2.0f - 1.0f) / d;
             c2 = c2 + ((float)bz * 2.0f - 1.0f) / d;
             p = node_index + bx * 4u + by * 2u + bz;
-            word = load_word(rs, p);
-            if (count) count_visit(a.count_nodes, a.n_words, p, word);
+            if (count) {
+                word = load_word_device_scope(rs, p);
+                count_visit(a.count_nodes, a.n_words, p, word);
+            } else {
+                word = load_word(rs, p);
+            }
             uint32_t tn = word >> 4;
             if (tn >= kVoxelOffset) break;
             if (depth >= kMaxDescent) { overflow = true; break; }
@@ -790,34 +822,94 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
 }
 
 // ---------------------------------------------------------------------------------------------
-// Counter scan, compute.wgsl:26-47.  One word per lane, wave-aggregated append (ballot + mbcnt,
-// one atomic per wave and list instead of one per node).
+// Counter scan, compute.wgsl:26-47 (the reference appends with one atomicAdd per node).
 // ---------------------------------------------------------------------------------------------
+// A workgroup takes chunks of kScanChunk words (2048 per wave, 4 words per lane and iteration, 16-byte loads) and
+// makes two passes over a chunk: count the candidates, reserve the list space of the whole chunk with ONE atomic
+// per list (one per wave and 64 words serialised at ~90 atomics/us: 4.8 ms for the 428 MB benchmark tree, 1 % of the
+// HBM roofline), then re-read the chunk (it is still in L2) and write the indices.  A list that is already full --
+// on a large tree nearly every interior node is an unsubdivide candidate -- is not touched any more: only the first
+// `capacity - 1` entries are ever used (adaptive.rs:22,86), so the count stops being maintained beyond that.
+constexpr uint32_t kScanChunk = 8192;
+
+__device__ __forceinline__ void scan_classify(uint32_t node, bool &is_sub, bool &is_unsub) {
+    const uint32_t counter = node & 15u;
+    is_unsub = node != 0u && counter == 0u && (node >> 4) < kVoxelOffset;            // compute.wgsl:40-42
+    is_sub = node != 0u && !is_unsub && counter >= 4u && (node >> 4) > kVoxelOffset;  // :43-46
+}
+
 __global__ __launch_bounds__(256) void scan_kernel(const uint32_t *nodes, uint32_t n_words, uint32_t node_length,
                                                    uint32_t *sub, uint32_t *unsub, uint32_t capacity) {
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t base = (blockIdx.x * 256u + threadIdx.x) & ~63u; base < n_words; base += gridDim.x * 256u) {
-        uint32_t id = base + lane;
-        uint32_t node = (id < n_words) ? nodes[id] : 0u;
-        uint32_t counter = node & 15u;
-        bool live = (node != 0u) && (id < node_length);
-        bool is_unsub = live && counter == 0u && (node >> 4) < kVoxelOffset;
-        bool is_sub = live && !is_unsub && counter >= 4u && (node >> 4) > kVoxelOffset;
-        uint64_t mu = __ballot(is_unsub), ms = __ballot(is_sub);
-        if (mu) {
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(&unsub[0], (uint32_t)__popcll(mu));
-            b = __builtin_amdgcn_readfirstlane(b);
-            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mu >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mu, 0u));
-            if (is_unsub && (uint64_t)b + rank + 1u < capacity) unsub[1u + b + rank] = id;
+    __shared__ uint32_t tot[2][4];
+    __shared__ uint32_t base[2];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t limit = min(n_words, node_length);  // `id < node_length` (compute.wgsl:41,44)
+    auto load4 = [&](uint32_t id, uint32_t (&v)[4]) {
+        if (id + 4u <= limit) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(nodes + id);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = (id + (uint32_t)k < limit) ? nodes[id + (uint32_t)k] : 0u;
         }
-        if (ms) {
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(&sub[0], (uint32_t)__popcll(ms));
-            b = __builtin_amdgcn_readfirstlane(b);
-            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
-            if (is_sub && (uint64_t)b + rank + 1u < capacity) sub[1u + b + rank] = id;
+    };
+    for (uint32_t chunk = blockIdx.x * kScanChunk; chunk < limit; chunk += gridDim.x * kScanChunk) {
+        const uint32_t w0 = chunk + wave * (kScanChunk / 4u);
+        uint32_t cs = 0, cu = 0;
+        for (uint32_t it = 0; it < kScanChunk / 4u / 256u; it++) {
+            uint32_t v[4];
+            load4(w0 + it * 256u + lane * 4u, v);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                bool a, b;
+                scan_classify(v[k], a, b);
+                cs += a ? 1u : 0u;
+                cu += b ? 1u : 0u;
+            }
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            cs += (uint32_t)__shfl_xor((int)cs, o);
+            cu += (uint32_t)__shfl_xor((int)cu, o);
+        }
+        if (lane == 0) { tot[0][wave] = cs; tot[1][wave] = cu; }
+        __syncthreads();
+        if (threadIdx.x < 2u) {
+            uint32_t *list = threadIdx.x == 0u ? sub : unsub;
+            const uint32_t n = tot[threadIdx.x][0] + tot[threadIdx.x][1] + tot[threadIdx.x][2] + tot[threadIdx.x][3];
+            uint32_t b = capacity;  // "full": nothing is written
+            if (n != 0u && __hip_atomic_load(&list[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u < capacity)
+                b = atomicAdd(&list[0], n);
+            base[threadIdx.x] = b;
+        }
+        __syncthreads();
+        uint32_t bs = base[0], bu = base[1];
+        for (uint32_t w = 0; w < wave; w++) { bs += tot[0][w]; bu += tot[1][w]; }
+        const bool write_s = cs != 0u && (uint64_t)bs + 1u < capacity, write_u = cu != 0u && (uint64_t)bu + 1u < capacity;
+        if (write_s || write_u) {  // wave-uniform
+            for (uint32_t it = 0; it < kScanChunk / 4u / 256u; it++) {
+                uint32_t v[4];
+                const uint32_t id = w0 + it * 256u + lane * 4u;
+                load4(id, v);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    bool a, b;
+                    scan_classify(v[k], a, b);
+                    const uint64_t ms = __ballot(a), mu = __ballot(b);
+                    if (write_s && ms) {
+                        const uint32_t r = bs + __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
+                        if (a && (uint64_t)r + 1u < capacity) sub[1u + r] = id + (uint32_t)k;
+                        bs += (uint32_t)__popcll(ms);
+                    }
+                    if (write_u && mu) {
+                        const uint32_t r = bu + __builtin_amdgcn_mbcnt_hi((uint32_t)(mu >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mu, 0u));
+                        if (b && (uint64_t)r + 1u < capacity) unsub[1u + r] = id + (uint32_t)k;
+                        bu += (uint32_t)__popcll(mu);
+                    }
+                }
+            }
+        }
+        __syncthreads();  // tot / base are reused by the next chunk
     }
 }
 
@@ -1194,8 +1286,8 @@ hipError_t launch_scan(const uint32_t *nodes, uint32_t n_words, uint32_t node_le
                        uint32_t capacity, hipStream_t stream) {
     (void)hipGetLastError();
     if (n_words == 0) return hipSuccess;
-    uint32_t blocks = (n_words + 255u) / 256u;
-    if (blocks > 2048u) blocks = 2048u;
+    uint32_t blocks = (n_words + kScanChunk - 1u) / kScanChunk;
+    if (blocks > 1024u) blocks = 1024u;  // 1024 chunks of 32 KiB in flight = the L2 capacity (second pass re-reads them)
     hipLaunchKernelGGL(scan_kernel, dim3(blocks), dim3(256), 0, stream, nodes, n_words, node_length, sub, unsub, capacity);
     return hipGetLastError();
 }

@@ -216,6 +216,31 @@ def test_scan_kernel(pkg, gpu, O):
     assert sub2.size == O.scan(words)[0][0]
 
 
+def test_scan_list_overflow_and_ragged_lengths(pkg, gpu, O):
+    """More candidates than a list holds: the read-back shows MAX - 1 entries (adaptive.rs:22,86), every one a real
+    candidate, none twice; the other list stays exact.  Plus lengths that are not multiples of the kernel's chunking."""
+    rng = np.random.default_rng(12)
+    n = 4_200_017
+    ptr = np.where(rng.random(n) < 0.6, rng.integers(1, 1 << 20, n), pkg.VOXEL_OFFSET + 1 + rng.integers(0, 1 << 24, n))
+    cnt = np.where(ptr < pkg.VOXEL_OFFSET, (rng.random(n) > 0.2).astype(np.int64), rng.integers(0, 16, n))  # a fifth of the interior nodes cold
+    words = ((ptr.astype(np.uint64) << 4) | cnt.astype(np.uint64)).astype(np.uint32)
+    render = pkg.Render(gpu, (8, 8), words, capacity=n)
+    compute = pkg.Compute(gpu, render)
+    osub, ounsub = O.scan(words, capacity=n + 1)  # exact candidate sets
+    want_sub, want_unsub = set(osub[1:1 + osub[0]].tolist()), set(ounsub[1:1 + ounsub[0]].tolist())
+    assert len(want_unsub) < pkg.compute.MAX_UNSUBDIVISIONS_PER_FRAME < len(want_sub)
+    compute.update(n)
+    sub, unsub = compute.read_lists()
+    assert sub.size == pkg.compute.MAX_SUBDIVISIONS_PER_FRAME - 1
+    assert np.unique(sub).size == sub.size and set(sub.tolist()) <= want_sub
+    assert set(unsub.tolist()) == want_unsub and unsub.size == len(want_unsub)
+    for node_length in (1, 3, 255, 8191, 8193, 100_003):
+        compute.update(node_length)
+        sub, unsub = compute.read_lists()
+        assert set(sub.tolist()) == {i for i in want_sub if i < node_length}
+        assert sorted(unsub.tolist()) == sorted(i for i in want_unsub if i < node_length)
+
+
 def test_error_paths(pkg, gpu):
     """Call-order and argument errors come back as statuses, not aborts."""
     g = pkg.Gpu(0)
