@@ -8,6 +8,7 @@
  *                                 create_buffer_init STORAGE|COPY_DST (render.rs:53-61)
  *   svo_nodes_write               queue.write_buffer(&render.node_buffer, 0, nodes)
  *                                 (app.rs:113-118, :163-168, :194-199, :239-244)
+ *   svo_nodes_scatter             the same upload restricted to the words that changed (no reference counterpart)
  *   svo_set_uniforms              Render::update -> queue.write_buffer(uniform_buffer)
  *                                 (render.rs:191-212); struct Uniforms (render.rs:287-322,
  *                                 shader.wgsl:2-13)
@@ -97,6 +98,8 @@ typedef enum svo_option {
                                 <= 16: default kernel; <= 23: deep-stack kernel; above: the general RESTART kernel */
     SVO_OPT_BLOCK_SHAPE = 10, /* log2 of the width of the 64-pixel blocks a wave works on (3: 8x8, 4: 16x4, ...) */
     SVO_OPT_DEBUG_BUFFER = 7, /* device pointer receiving 8 words per wave: start, queue-dry, end (10 ns ticks), rounds, ... */
+    SVO_OPT_SCAN_CLEARS_COUNTERS = 11, /* 1: svo_scan_dispatch also zeroes the hit counters it has scanned, so that the
+                                          host need not re-upload the whole array to reset them (svo_nodes_scatter) */
     SVO_OPT_PRIO_STEPS = 6   /* accepted and ignored: raising the issue priority of waves with old rays measured no effect and
                                 left the kernel */
 } svo_option;
@@ -114,6 +117,11 @@ int svo_nodes_alloc(svo_ctx *ctx, size_t capacity_words);
 /* Use caller-owned device memory as the node buffer instead (no copy). */
 int svo_nodes_bind_device(svo_ctx *ctx, uint32_t *device_words, size_t capacity_words);
 int svo_nodes_write(svo_ctx *ctx, size_t word_offset, const uint32_t *host_words, size_t n);
+/* Incremental form of the reference's per-frame `queue.write_buffer(&node_buffer, 0, nodes)` (app.rs:113-118): write
+ * host_words[i] to word indices[i] (host pointers, n pairs, indices unique), e.g. the words the streaming loop changed
+ * (svo_octree_take_dirty).  Asynchronous on the ctx stream like svo_nodes_write: both arrays must stay valid until the
+ * next blocking call. */
+int svo_nodes_scatter(svo_ctx *ctx, const uint32_t *indices, const uint32_t *host_words, size_t n);
 int svo_nodes_read(svo_ctx *ctx, size_t word_offset, uint32_t *host_words, size_t n);
 /* Device pointer of the node buffer (for zero-copy consumers). */
 int svo_nodes_device_ptr(svo_ctx *ctx, uint32_t **out, size_t *capacity_words);

@@ -85,6 +85,10 @@ void svo_octree_pos_offset(uint32_t child_index, uint32_t depth, float out[3]);
 size_t svo_octree_holes(const svo_octree *o);
 void svo_octree_set_node(svo_octree *o, size_t index, uint32_t word);   /* octree.nodes[i] = word (adaptive.rs:117) */
 void svo_octree_position(const svo_octree *o, size_t index, float out[3]); /* octree.positions[i] */
+/* Words written (subdivide, unsubdivide, set_node, svo_adaptive_*) since the previous call, each index once, with
+ * their current values: the input of svo_nodes_scatter.  Returns the count; with NULL outputs or cap too small nothing
+ * is consumed. */
+size_t svo_octree_take_dirty(svo_octree *o, uint32_t *indices, uint32_t *words, size_t cap);
 
 /* ---- World: chunks, block instancing, chunk dumps ---- */
 typedef struct svo_world svo_world;

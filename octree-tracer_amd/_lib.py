@@ -39,7 +39,7 @@ class TerrainParams(C.Structure):
 
 DEVICE_SYMBOLS = [
     "svo_ctx_create", "svo_ctx_destroy", "svo_ctx_set_stream", "svo_set_option", "svo_last_error", "svo_sync",
-    "svo_nodes_alloc", "svo_nodes_bind_device", "svo_nodes_write", "svo_nodes_read", "svo_nodes_device_ptr",
+    "svo_nodes_alloc", "svo_nodes_bind_device", "svo_nodes_write", "svo_nodes_scatter", "svo_nodes_read", "svo_nodes_device_ptr",
     "svo_set_uniforms", "svo_render", "svo_render_host", "svo_render_tiles", "svo_render_secondary", "svo_render_tiles_secondary", "svo_trace_rays",
     "svo_last_render_ms", "svo_timing_collect", "svo_diag_gather", "svo_scan_dispatch", "svo_scan_read",
 ]
@@ -51,7 +51,7 @@ HOST_SYMBOLS = [
     "svo_cpu_octree_generate_mips", "svo_vox_parse", "svo_vox_write", "svo_rsvo_write",
     "svo_octree_new", "svo_octree_from_words", "svo_octree_free", "svo_octree_len", "svo_octree_raw_data",
     "svo_octree_get_node", "svo_octree_subdivide", "svo_octree_unsubdivide", "svo_octree_find_voxel",
-    "svo_octree_expanded", "svo_octree_pos_offset", "svo_octree_holes", "svo_octree_set_node", "svo_octree_position", "svo_camera_matrices",
+    "svo_octree_expanded", "svo_octree_pos_offset", "svo_octree_holes", "svo_octree_set_node", "svo_octree_position", "svo_octree_take_dirty", "svo_camera_matrices",
     "svo_world_new", "svo_world_free", "svo_world_last_error", "svo_world_insert", "svo_world_remove",
     "svo_world_chunk", "svo_world_chunk_ids", "svo_world_find_voxel", "svo_world_generate_mip_tree",
     "svo_world_save_chunk", "svo_world_load_chunk", "svo_world_load", "svo_cpu_octree_bin", "svo_cpu_octree_from_bin",
@@ -90,6 +90,7 @@ def lib():
     sig("svo_nodes_alloc", C.c_int, vp, sz)
     sig("svo_nodes_bind_device", C.c_int, vp, vp, sz)
     sig("svo_nodes_write", C.c_int, vp, sz, vp, sz)
+    sig("svo_nodes_scatter", C.c_int, vp, vp, vp, sz)
     sig("svo_nodes_read", C.c_int, vp, sz, vp, sz)
     sig("svo_nodes_device_ptr", C.c_int, vp, C.POINTER(vp), C.POINTER(sz))
     sig("svo_set_uniforms", C.c_int, vp, C.POINTER(Uniforms))
@@ -136,6 +137,7 @@ def lib():
     sig("svo_octree_holes", sz, vp)
     sig("svo_octree_set_node", None, vp, sz, u32)
     sig("svo_octree_position", None, vp, sz, fp)
+    sig("svo_octree_take_dirty", sz, vp, vp, vp, sz)
     sig("svo_world_new", vp, cp)
     sig("svo_world_free", None, vp)
     sig("svo_world_last_error", cp, vp)

@@ -4,6 +4,7 @@ The list processing itself is native (svo_adaptive_subdivide / svo_adaptive_unsu
 import numpy as np
 
 from ._lib import lib
+from .gpu import OPT_SCAN_CLEARS_COUNTERS
 from .world import World as _World
 
 
@@ -36,10 +37,18 @@ def process_unsubdivision(compute_lists, octree, world):
 
 
 class AdaptiveLoop:
-    """App::update (app.rs:94-118): uniforms -> trace (counters live) -> scan -> CPU (un)subdivide -> re-upload."""
+    """App::update (app.rs:94-118): uniforms -> trace (counters live) -> scan -> CPU (un)subdivide -> re-upload.
 
-    def __init__(self, gpu, render, compute, octree, world):
+    incremental=True replaces the reference's re-upload of the WHOLE array (which is also what resets the hit
+    counters: host words carry counter 0) by its device-side equivalent: the scan zeroes the counters it has read
+    (SVO_OPT_SCAN_CLEARS_COUNTERS) and only the words the list processing changed are sent (svo_nodes_scatter).
+    The device array after a frame is the same either way."""
+
+    def __init__(self, gpu, render, compute, octree, world, incremental=False):
         self.gpu, self.render, self.compute, self.octree, self.world = gpu, render, compute, octree, world
+        self.incremental = incremental
+        gpu.set_option(OPT_SCAN_CLEARS_COUNTERS, 1 if incremental else 0)
+        octree.take_dirty()  # the device already holds the octree as it is now
 
     def frame(self, settings, character, deterministic=False):
         self.render.update(settings, character)
@@ -53,6 +62,10 @@ class AdaptiveLoop:
             unsub.sort()
         n_sub = process_subdivision(sub, self.octree, self.world)
         n_unsub = process_unsubdivision(unsub, self.octree, self.world)
-        # app.rs:113-118: the whole array goes back (host words carry counter 0, which also clears the counters)
-        self.render.write_nodes(self.octree.raw_data())
+        if self.incremental:
+            idx, val = self.octree.take_dirty()
+            self.render.scatter_nodes(idx, val, node_length=len(self.octree))
+        else:
+            # app.rs:113-118: the whole array goes back (host words carry counter 0, which also clears the counters)
+            self.render.write_nodes(self.octree.raw_data())
         return hits, n_sub, n_unsub

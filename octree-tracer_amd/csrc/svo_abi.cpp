@@ -38,6 +38,9 @@ struct svo_ctx {
     int variant = SVO_VARIANT_STACK;
     int grid_blocks = 0;
     uint32_t refill_min = 12;
+    bool scan_clears = false;
+    void *scatter_buf = nullptr;
+    size_t scatter_bytes = 0;
     uint32_t prio_steps = 0;
     uint32_t block_w_log2 = 3;  // 64-pixel blocks of 8x8
     uint32_t tree_depth = 16;  // caller's bound on the octree depth (the reference's Settings.octree_depth)
@@ -409,7 +412,7 @@ int svo_ctx_destroy(svo_ctx *ctx) {
         if (sc.cost) (void)hipFree(sc.cost);
         if (sc.order) (void)hipFree(sc.order);
     }
-    for (void *p : {ctx->shade_hits, ctx->shade_aux, ctx->shade_rays, ctx->shade_shadow})
+    for (void *p : {ctx->shade_hits, ctx->shade_aux, ctx->shade_rays, ctx->shade_shadow, ctx->scatter_buf})
         if (p) (void)hipFree(p);
     if (ctx->scan_sub) (void)hipFree(ctx->scan_sub);
     if (ctx->scan_unsub) (void)hipFree(ctx->scan_unsub);
@@ -457,6 +460,9 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
         case SVO_OPT_REFILL_MIN:
             if (value < 1 || value > 64) return fail(ctx, SVO_ERR_ARG, "refill_min must be 1..64");
             ctx->refill_min = (uint32_t)value;
+            return SVO_OK;
+        case SVO_OPT_SCAN_CLEARS_COUNTERS:
+            ctx->scan_clears = value != 0;
             return SVO_OK;
         case SVO_OPT_STRIP_ITEMS:
             if (value < 64 || value > 2048 || (value & 63)) return fail(ctx, SVO_ERR_ARG, "strip_items must be a multiple of 64 in [64, 2048]");
@@ -556,6 +562,24 @@ int svo_nodes_write(svo_ctx *ctx, size_t word_offset, const uint32_t *host_words
     if (n)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->nodes + word_offset, host_words, n * sizeof(uint32_t), hipMemcpyHostToDevice,
                                     ctx->stream));
+    ctx->top_dirty = true;
+    return SVO_OK;
+}
+
+int svo_nodes_scatter(svo_ctx *ctx, const uint32_t *indices, const uint32_t *host_words, size_t n) {
+    if (!ctx || ((!indices || !host_words) && n)) return SVO_ERR_ARG;
+    if (!ctx->nodes) return fail(ctx, SVO_ERR_STATE, "svo_nodes_alloc not called");
+    if (n > (1u << 28)) return fail(ctx, SVO_ERR_ARG, "too many words for one scatter");
+    for (size_t i = 0; i < n; i++)
+        if (indices[i] >= ctx->capacity) return fail(ctx, SVO_ERR_ARG, "scatter index past the node buffer capacity");
+    int rc = bind(ctx);
+    if (rc || n == 0) return rc;
+    rc = ensure_dev(ctx, &ctx->scatter_buf, &ctx->scatter_bytes, 2 * n * sizeof(uint32_t));
+    if (rc) return rc;
+    uint32_t *d_idx = (uint32_t *)ctx->scatter_buf, *d_val = d_idx + n;
+    HIP_TRY(ctx, hipMemcpyAsync(d_idx, indices, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_val, host_words, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, svo::launch_scatter(ctx->nodes, (uint32_t)ctx->capacity, d_idx, d_val, (uint32_t)n, ctx->stream));
     ctx->top_dirty = true;
     return SVO_OK;
 }
@@ -713,7 +737,7 @@ int svo_scan_dispatch(svo_ctx *ctx, uint32_t node_length) {
     }
     uint32_t n = node_length < ctx->capacity ? node_length : (uint32_t)ctx->capacity;
     HIP_TRY(ctx, svo::launch_scan(ctx->nodes, n, node_length, ctx->scan_sub, ctx->scan_unsub,
-                                  (uint32_t)ctx->scan_capacity, ctx->stream));
+                                  (uint32_t)ctx->scan_capacity, ctx->scan_clears, ctx->stream));
     return SVO_OK;
 }
 

@@ -80,7 +80,9 @@ hipError_t launch_secondary_gen(const TraceArgs &args, const float *aux_t, float
 hipError_t launch_shade(const TraceArgs &args, const svo_hit *shadow_hits, uint32_t *rgba, hipStream_t stream);
 hipError_t launch_diag_gather(const uint32_t *buf, uint32_t n_words, uint32_t stride_words, uint32_t n_loads, uint32_t *sink,
                               hipStream_t stream);
-hipError_t launch_scan(const uint32_t *nodes, uint32_t n_words, uint32_t node_length, uint32_t *sub,
-                       uint32_t *unsub, uint32_t capacity, hipStream_t stream);
+hipError_t launch_scan(uint32_t *nodes, uint32_t n_words, uint32_t node_length, uint32_t *sub, uint32_t *unsub,
+                       uint32_t capacity, bool clear_counters, hipStream_t stream);
+hipError_t launch_scatter(uint32_t *nodes, uint32_t n_words, const uint32_t *indices, const uint32_t *words, uint32_t n,
+                          hipStream_t stream);
 
 }  // namespace svo

@@ -404,6 +404,13 @@ struct svo_octree {
     std::vector<uint32_t> nodes;
     std::vector<Vec3> positions;
     std::vector<size_t> hole_stack;
+    // words written since the last svo_octree_take_dirty (each index once): what an incremental upload has to send
+    std::vector<uint32_t> dirty;
+    std::vector<uint8_t> dirty_flag;
+    void touch(size_t i) {
+        if (dirty_flag.size() < nodes.size()) dirty_flag.resize(nodes.size(), 0);
+        if (!dirty_flag[i]) { dirty_flag[i] = 1; dirty.push_back(uint32_t(i)); }
+    }
 };
 
 extern "C" {
@@ -443,7 +450,7 @@ size_t svo_octree_len(const svo_octree *o) { return o->nodes.size(); }
 const uint32_t *svo_octree_raw_data(const svo_octree *o) { return o->nodes.data(); }
 uint32_t svo_octree_get_node(const svo_octree *o, size_t index) { return o->nodes[index] >> 4; }
 size_t svo_octree_holes(const svo_octree *o) { return o->hole_stack.size(); }
-void svo_octree_set_node(svo_octree *o, size_t index, uint32_t word) { o->nodes[index] = word; }
+void svo_octree_set_node(svo_octree *o, size_t index, uint32_t word) { o->nodes[index] = word; o->touch(index); }
 void svo_octree_position(const svo_octree *o, size_t index, float out[3]) {
     out[0] = o->positions[index].x; out[1] = o->positions[index].y; out[2] = o->positions[index].z;
 }
@@ -461,10 +468,12 @@ int svo_octree_subdivide(svo_octree *o, size_t node, const uint8_t mask_rgb[24],
         o->positions.resize(first + 8);
     }
     o->nodes[node] = uint32_t(first) << 4;
+    o->touch(node);
     for (uint32_t i = 0; i < 8; i++) {
         const Vec3 off = pos_offset(i, depth);
         o->nodes[first + i] = Rgb{mask_rgb[3 * i], mask_rgb[3 * i + 1], mask_rgb[3 * i + 2]}.gpu_word();
         o->positions[first + i] = Vec3{c.x + off.x, c.y + off.y, c.z + off.z};
+        o->touch(first + i);
     }
     return 0;
 }
@@ -476,6 +485,7 @@ int svo_octree_unsubdivide(svo_octree *o, size_t node) {
     if (c.x == 0.0f && c.y == 0.0f && c.z == 0.0f) return -1;  // octree.rs:104-107
     o->hole_stack.push_back(ptr);
     o->nodes[node] = Rgb{255, 0, 0}.gpu_word();  // octree.rs:109
+    o->touch(node);
     return 0;
 }
 
@@ -487,6 +497,18 @@ void svo_octree_find_voxel(const svo_octree *o, const float pos[3], int64_t max_
     if (index) *index = l.index;
     if (depth) *depth = l.depth;
     if (node_pos) { node_pos[0] = l.pos.x; node_pos[1] = l.pos.y; node_pos[2] = l.pos.z; }
+}
+
+size_t svo_octree_take_dirty(svo_octree *o, uint32_t *indices, uint32_t *words, size_t cap) {
+    const size_t n = o->dirty.size();
+    if (!indices || !words || cap < n) return n;
+    for (size_t k = 0; k < n; k++) {
+        indices[k] = o->dirty[k];
+        words[k] = o->nodes[o->dirty[k]];
+        o->dirty_flag[o->dirty[k]] = 0;
+    }
+    o->dirty.clear();
+    return n;
 }
 
 int svo_octree_expanded(const svo_octree *o, size_t size, uint32_t *out) {
@@ -778,6 +800,7 @@ int64_t svo_adaptive_unsubdivide(svo_world *w, svo_octree *o, const uint32_t *li
             if (id >= kChunkOffset / 2) svo_world_remove(w, id);
         }
         o->nodes[node_index] = node.value.gpu_word();  // :117
+        o->touch(node_index);
         done += r == 0;
     }
     return done;

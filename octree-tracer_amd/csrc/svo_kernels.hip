@@ -829,8 +829,11 @@ __device__ __forceinline__ void scan_classify(uint32_t node, bool &is_sub, bool 
     is_sub = node != 0u && !is_unsub && counter >= 4u && (node >> 4) > kVoxelOffset;  // :43-46
 }
 
-__global__ __launch_bounds__(256) void scan_kernel(const uint32_t *nodes, uint32_t n_words, uint32_t node_length,
-                                                   uint32_t *sub, uint32_t *unsub, uint32_t capacity) {
+// clear_counters (SVO_OPT_SCAN_CLEARS_COUNTERS): the second pass also zeroes the hit counters it has just classified.
+// The reference gets that effect from re-uploading the whole array with counter-free host words every frame
+// (app.rs:113-118); with this flag the host only sends the words it changed (svo_nodes_scatter).
+__global__ __launch_bounds__(256) void scan_kernel(uint32_t *nodes, uint32_t n_words, uint32_t node_length,
+                                                   uint32_t *sub, uint32_t *unsub, uint32_t capacity, bool clear_counters) {
     __shared__ uint32_t tot[2][4];
     __shared__ uint32_t base[2];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -877,11 +880,20 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t *nodes, uint32
         uint32_t bs = base[0], bu = base[1];
         for (uint32_t w = 0; w < wave; w++) { bs += tot[0][w]; bu += tot[1][w]; }
         const bool write_s = cs != 0u && (uint64_t)bs + 1u < capacity, write_u = cu != 0u && (uint64_t)bu + 1u < capacity;
-        if (write_s || write_u) {  // wave-uniform
+        if (write_s || write_u || clear_counters) {  // wave-uniform
             for (uint32_t it = 0; it < kScanChunk / 4u / 256u; it++) {
                 uint32_t v[4];
                 const uint32_t id = w0 + it * 256u + lane * 4u;
                 load4(id, v);
+                if (clear_counters && ((v[0] | v[1] | v[2] | v[3]) & 15u)) {
+                    if (id + 4u <= limit) {
+                        *reinterpret_cast<uint4 *>(nodes + id) = make_uint4(v[0] & ~15u, v[1] & ~15u, v[2] & ~15u, v[3] & ~15u);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (id + (uint32_t)k < limit) nodes[id + (uint32_t)k] = v[k] & ~15u;
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     bool a, b;
@@ -1273,13 +1285,32 @@ hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cos
     return hipGetLastError();
 }
 
-hipError_t launch_scan(const uint32_t *nodes, uint32_t n_words, uint32_t node_length, uint32_t *sub, uint32_t *unsub,
-                       uint32_t capacity, hipStream_t stream) {
+__global__ __launch_bounds__(256) void scatter_kernel(uint32_t *nodes, uint32_t n_words, const uint32_t *indices,
+                                                      const uint32_t *words, uint32_t n) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t at = indices[i];
+        if (at < n_words) nodes[at] = words[i];
+    }
+}
+
+hipError_t launch_scatter(uint32_t *nodes, uint32_t n_words, const uint32_t *indices, const uint32_t *words, uint32_t n,
+                          hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n == 0) return hipSuccess;
+    uint32_t blocks = (n + 255u) / 256u;
+    if (blocks > 2048u) blocks = 2048u;
+    hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), 0, stream, nodes, n_words, indices, words, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(uint32_t *nodes, uint32_t n_words, uint32_t node_length, uint32_t *sub, uint32_t *unsub,
+                       uint32_t capacity, bool clear_counters, hipStream_t stream) {
     (void)hipGetLastError();
     if (n_words == 0) return hipSuccess;
     uint32_t blocks = (n_words + kScanChunk - 1u) / kScanChunk;
     if (blocks > 1024u) blocks = 1024u;  // 1024 chunks of 32 KiB in flight = the L2 capacity (second pass re-reads them)
-    hipLaunchKernelGGL(scan_kernel, dim3(blocks), dim3(256), 0, stream, nodes, n_words, node_length, sub, unsub, capacity);
+    hipLaunchKernelGGL(scan_kernel, dim3(blocks), dim3(256), 0, stream, nodes, n_words, node_length, sub, unsub, capacity,
+                       clear_counters);
     return hipGetLastError();
 }
 

@@ -109,6 +109,15 @@ class Octree:
         lib().svo_octree_position(self._h, index, out)
         return tuple(out)
 
+    def take_dirty(self):
+        """(indices, words) written since the previous call, each index once: the input of Render.scatter_nodes."""
+        n = lib().svo_octree_take_dirty(self._h, None, None, 0)
+        idx = np.empty(n, dtype=np.uint32)
+        val = np.empty(n, dtype=np.uint32)
+        if n:
+            lib().svo_octree_take_dirty(self._h, idx.ctypes.data, val.ctypes.data, n)
+        return idx, val
+
     def hole_count(self):
         return lib().svo_octree_holes(self._h)
 

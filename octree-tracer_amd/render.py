@@ -62,6 +62,17 @@ class Render:
         self.gpu.sync()  # the host array may be released by the caller
         self.node_length = max(self.node_length, offset + words.size)
 
+    def scatter_nodes(self, indices, words, node_length=None):
+        """Incremental upload: words[i] -> node buffer [indices[i]] (svo_nodes_scatter)."""
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        self.gpu.check(lib().svo_nodes_scatter(self.gpu._h, indices.ctypes.data, words.ctypes.data, indices.size))
+        self.gpu.sync()  # the host arrays may be released by the caller
+        if indices.size:
+            self.node_length = max(self.node_length, int(indices.max()) + 1)
+        if node_length is not None:
+            self.node_length = max(self.node_length, node_length)
+
     def read_nodes(self, n=None, offset=0):
         n = self.node_length if n is None else n
         out = np.empty(n, dtype=np.uint32)

@@ -389,6 +389,40 @@ def test_adaptive_streaming_loop(pkg, gpu, O, monu9_words):
     assert (n_sub, n_unsub) == (0, 0) and len(octree) == sizes[-1]
 
 
+def test_adaptive_loop_incremental_upload(pkg, gpu, O):
+    """The streaming loop with the device-side reset (scan clears the counters it read, only changed words are sent,
+    svo_nodes_scatter) against the reference's form (whole array re-uploaded every frame, app.rs:113-118): same lists,
+    same host tree, and the SAME device array after every frame -- counters included."""
+    from conftest import load_vox_fixture
+    size, xyzi, pal, n, _ = load_vox_fixture("monu9")
+    loops = []
+    for incremental in (False, True):
+        g = pkg.Gpu(0)
+        world = pkg.adaptive.World(pkg.CpuOctree.from_voxels(size, xyzi, pal))
+        octree = world.root_octree()
+        render = pkg.Render.new(g, (160, 96), octree, capacity=200_000)
+        render.set_flags(pause_adaptive=False, shadows=True)
+        compute = pkg.Compute.new(g, render)
+        loops.append((g, render, octree, pkg.adaptive.AdaptiveLoop(g, render, compute, octree, world, incremental=incremental)))
+    settings = pkg.Settings()
+    for frame in range(10):
+        character = pkg.Character((0.1 + 0.02 * frame, 0.2, -1.5), (0.0, 0.0, 1.5))  # a moving camera: unsubdivisions too
+        results = []
+        for g, render, octree, loop in loops:
+            hits, n_sub, n_unsub = loop.frame(settings, character, deterministic=True)
+            g.sync()
+            results.append((pkg.render.hits_to_numpy(hits).view(np.uint32).copy(), n_sub, n_unsub, octree.raw_data(),
+                            render.read_nodes(len(octree))))
+        a, b = results
+        assert np.array_equal(a[0], b[0]), f"frame {frame}: records differ"
+        assert a[1:3] == b[1:3] and np.array_equal(a[3], b[3])
+        assert np.array_equal(a[4], b[4]), f"frame {frame}: device arrays differ"
+        assert (b[4] & 15 == 0).all() and np.array_equal(b[4], b[3])  # counters reset, device == host tree
+    assert len(loops[1][2]) > 1000
+    for g, *_ in loops:
+        g.close()
+
+
 def test_config3_rsvo_shell(pkg, gpu, O):
     """Config 3 stand-in (files/statuette.rsvo is absent from the checkout): a sphere shell voxelised at depth 8,
     serialised as an .rsvo child-mask stream, loaded by load_octree at two depths (cpu_octree.rs:128-175) and traced."""

@@ -107,16 +107,31 @@ def test_streaming_lists_against_restatement(pkg, O):
         pick = rng.permutation(leaves)[:max(4, leaves.size // 3)].astype(np.uint32)
         if rnd % 2:
             pick = np.concatenate([pick, pick[:3]])  # duplicates: "Doubleup!" (:32-35)
+        before = octree.raw_data()
         n = pkg.adaptive.process_subdivision(pick, octree, world)
         WO.process_subdivision(pick.tolist(), ooctree, oworld)
         assert octree.raw_data().tolist() == ooctree.nodes, f"round {rnd}"
         assert n > 0
+        if rnd == 0:
+            octree.take_dirty()  # (words written while the root tree was built)
+        else:
+            # the dirty set is exactly what an incremental upload must send: applying it to the old array gives the new one
+            idx, val = octree.take_dirty()
+            assert np.unique(idx).size == idx.size
+            patched = np.concatenate([before, np.zeros(len(octree) - before.size, dtype=np.uint32)])
+            patched[idx] = val
+            assert np.array_equal(patched, octree.raw_data())
+            assert octree.take_dirty()[0].size == 0
         if rnd in (2, 4):  # collapse some interior nodes again; the freed groups are reused next round
             interior = np.flatnonzero(((octree.raw_data() >> 4) < pkg.VOXEL_OFFSET))
             drop = rng.permutation(interior)[:5].astype(np.uint32)
+            before = octree.raw_data()
             pkg.adaptive.process_unsubdivision(drop, octree, world)
             WO.process_unsubdivision(drop.tolist(), ooctree, oworld)
             assert octree.raw_data().tolist() == ooctree.nodes
+            idx, val = octree.take_dirty()
+            before[idx] = val
+            assert np.array_equal(before, octree.raw_data()) and set(idx.tolist()) == set(drop.tolist())
             assert octree.hole_count() == len(ooctree.hole_stack) > 0
     for i in rng.integers(0, len(octree), 64).tolist():
         assert octree.position(i) == ooctree.positions[i]
