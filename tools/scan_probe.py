@@ -28,3 +28,21 @@ for mode, flags in (("counters all zero (static tree)", dict(pause_adaptive=True
     m = float(np.median(ms[1:]))
     print(f"{mode}: trace {t_trace:.3f} ms; scan {m:.4f} ms = {words.nbytes / m / 1e6:.0f} GB/s over {words.nbytes / 1e6:.0f} MB; "
           f"lists {sub.size} / {unsub.size}", flush=True)
+
+# the reference's per-frame upload against its incremental form
+gpu.set_option(pkg.gpu.OPT_SCAN_CLEARS_COUNTERS, 1)
+render.set_flags(pause_adaptive=False, shadows=False)
+render.update(pkg.Settings(), pkg.Character(cam, look))
+render.render()
+rng = np.random.default_rng(0)
+idx = np.unique(rng.integers(0, words.size, 540_000)).astype(np.uint32)  # ~60 k subdivisions x 9 words
+val = words[idx]
+gpu.sync()
+for name, fn in (("full re-upload (svo_nodes_write, 428 MB)", lambda: render.write_nodes(words)),
+                 ("scan with counter reset + svo_nodes_scatter of 540 k words", lambda: (compute.update(int(words.size)), render.scatter_nodes(idx, val)))):
+    ts = []
+    for _ in range(4):
+        render.render(); gpu.sync()
+        t0 = time.perf_counter(); fn(); gpu.sync(); ts.append(time.perf_counter() - t0)
+    print(f"{name}: {np.median(ts) * 1e3:.2f} ms", flush=True)
+assert (render.read_nodes(words.size) & 15 == 0).all()
