@@ -130,8 +130,9 @@ def main():
         # frame i's RCCL gather overlaps frame i+1's trace (double-buffered); rank 0 un-permutes each frame
         if a.backend == "nccl":
             traces = [(lambda buf, r=r: r.render_tiles(tw, th, rank, world, hits=buf)) for _, r, _ in lanes]
+            assemble = [(lambda g, out, r=r: r.assemble_tiles(g, tw, th, out=out)) for _, r, _ in lanes]
             pipe = pkg.sharding.FramePipeline(traces, W, H, tw, th, rank, world, f"cuda:{local_rank}",
-                                              streams=[s for _, _, s in lanes])
+                                              streams=[s for _, _, s in lanes], assemble=assemble)
         else:
             n_pad_v = pkg.sharding.padded_tile_count(W, H, tw, th, world)
 

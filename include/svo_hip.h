@@ -158,6 +158,10 @@ int svo_render_secondary(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t
 int svo_render_tiles_secondary(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t tile_w,
                                uint32_t tile_h, uint32_t first_tile, uint32_t tile_stride,
                                uint32_t n_secondary, svo_hit *primary_out, svo_hit *secondary_out);
+/* Rank 0 after the frame-end gather: `gathered` holds world x n_pad tiles (rank r's k-th tile = tile r + k * world, the
+ * layout svo_render_tiles writes); frame_out receives the row-major width x height frame.  Device pointers. */
+int svo_assemble_tiles(svo_ctx *ctx, const svo_hit *gathered, uint32_t world, uint32_t n_pad, uint32_t width,
+                       uint32_t height, uint32_t tile_w, uint32_t tile_h, svo_hit *frame_out);
 /* octree_ray over n explicit rays (6 floats each: pos.xyz, dir.xyz; device pointers). */
 int svo_trace_rays(svo_ctx *ctx, const float *rays, size_t n_rays, svo_hit *hits_out);
 

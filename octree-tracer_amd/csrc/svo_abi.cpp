@@ -672,6 +672,20 @@ int svo_render_tiles_secondary(svo_ctx *ctx, uint32_t width, uint32_t height, ui
     return trace_secondary(ctx, work, n_secondary, primary_out, secondary_out);
 }
 
+int svo_assemble_tiles(svo_ctx *ctx, const svo_hit *gathered, uint32_t world, uint32_t n_pad, uint32_t width, uint32_t height,
+                       uint32_t tile_w, uint32_t tile_h, svo_hit *frame_out) {
+    if (!ctx || !gathered || !frame_out) return SVO_ERR_ARG;
+    if (world == 0 || tile_w == 0 || tile_h == 0 || width % tile_w || height % tile_h)
+        return fail(ctx, SVO_ERR_ARG, "frame must be a whole number of tiles");
+    const uint64_t tiles = (uint64_t)(width / tile_w) * (height / tile_h);
+    if ((uint64_t)n_pad * world < tiles) return fail(ctx, SVO_ERR_ARG, "gathered buffer holds fewer tiles than the frame");
+    if ((uint64_t)width * height > (1u << 26)) return fail(ctx, SVO_ERR_ARG, "frame too large");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, svo::launch_assemble_tiles(gathered, frame_out, world, n_pad, width, height, tile_w, tile_h, ctx->stream));
+    return SVO_OK;
+}
+
 int svo_trace_rays(svo_ctx *ctx, const float *rays, size_t n_rays, svo_hit *hits_out) {
     if (!ctx || (!rays && n_rays)) return SVO_ERR_ARG;
     if (n_rays > (1u << 26)) return fail(ctx, SVO_ERR_ARG, "too many rays for one call");

@@ -1285,6 +1285,29 @@ hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cos
     return hipGetLastError();
 }
 
+// Un-permute a gathered, tile-sharded frame (rank r, slot k holds tile r + k * world, row-major inside the tile) into
+// the row-major frame: one 16-byte record per thread, 64-pixel tile rows stay contiguous on both sides.
+__global__ __launch_bounds__(256) void assemble_tiles_kernel(const uint4 *gathered, uint4 *frame, uint32_t world, uint32_t n_pad,
+                                                             uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h) {
+    const uint32_t tiles_x = width / tile_w, n = width * height;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t y = i / width, x = i - y * width;
+        const uint32_t ty = y / tile_h, tx = x / tile_w;
+        const uint32_t t = ty * tiles_x + tx, r = t % world, k = t / world;
+        frame[i] = gathered[((uint64_t)r * n_pad + k) * (tile_w * tile_h) + (y - ty * tile_h) * tile_w + (x - tx * tile_w)];
+    }
+}
+
+hipError_t launch_assemble_tiles(const svo_hit *gathered, svo_hit *frame, uint32_t world, uint32_t n_pad, uint32_t width,
+                                 uint32_t height, uint32_t tile_w, uint32_t tile_h, hipStream_t stream) {
+    (void)hipGetLastError();
+    uint32_t blocks = (width * height + 255u) / 256u;
+    if (blocks > 8192u) blocks = 8192u;
+    hipLaunchKernelGGL(assemble_tiles_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(gathered),
+                       reinterpret_cast<uint4 *>(frame), world, n_pad, width, height, tile_w, tile_h);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void scatter_kernel(uint32_t *nodes, uint32_t n_words, const uint32_t *indices,
                                                       const uint32_t *words, uint32_t n) {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {

@@ -155,6 +155,17 @@ class Render:
                                                         n_secondary, hits.data_ptr(), secondary.data_ptr()))
         return hits, secondary
 
+    def assemble_tiles(self, gathered, tile_w, tile_h, out=None):
+        """Rank 0: un-permute a gathered frame ([world, n_pad, tile_h * tile_w, 4] int32, device) into the row-major frame
+        ([H, W, 4]) with one kernel on this context's stream (svo_assemble_tiles)."""
+        w, h = self.size
+        world, n_pad = int(gathered.shape[0]), int(gathered.shape[1])
+        if out is None:
+            out = torch.empty((h, w, 4), dtype=torch.int32, device=gathered.device)
+        self.gpu.check(lib().svo_assemble_tiles(self.gpu._h, gathered.data_ptr(), world, n_pad, w, h, tile_w, tile_h,
+                                                out.data_ptr()))
+        return out
+
     def render_host(self, tile=None, rgba=False):
         """Blocking variant with host results: hit records (numpy structured array, tile-local row-major)
         and, with rgba=True, also the shaded RGBA8 image of fs_main (uint8 [h, w, 4])."""

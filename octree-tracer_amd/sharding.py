@@ -58,10 +58,15 @@ class FramePipeline:
     alone and 0.085 ms with three frames in flight).
 
     step() returns the most recent COMPLETED frame on rank 0 (None until the first one is ready, and on
-    other ranks); drain() completes what is in flight and returns the last frame."""
+    other ranks; with `assemble` it lives in a buffer that is reused after as many further steps as there are
+    buffers); drain() completes what is in flight and returns the last frame."""
 
-    def __init__(self, trace, width, height, tile_w, tile_h, rank, world, device, group=None, streams=None):
+    def __init__(self, trace, width, height, tile_w, tile_h, rank, world, device, group=None, streams=None, assemble=None):
+        """assemble (optional, rank 0): one callable per lane, `assemble(gathered, out) -> out`, that un-permutes a gathered
+        frame on the lane's stream (Render.assemble_tiles: one kernel, a few microseconds of host time); without it the
+        generic torch expression assemble_frame() is used."""
         self.traces = list(trace) if isinstance(trace, (list, tuple)) else [trace]
+        self.assemble = list(assemble) if assemble is not None else None
         self.streams = list(streams) if streams is not None else None
         if self.streams is not None and len(self.streams) != len(self.traces):
             raise ValueError("one stream per lane")
@@ -72,6 +77,8 @@ class FramePipeline:
         self.local = [torch.zeros((n_pad, tile_h * tile_w, 4), dtype=torch.int32, device=device) for _ in range(self.n_buf)]
         self.gathered = [torch.empty((world, n_pad, tile_h * tile_w, 4), dtype=torch.int32, device=device)
                          if rank == 0 else None for _ in range(self.n_buf)]
+        self.frames = [torch.empty((height, width, 4), dtype=torch.int32, device=device) if (rank == 0 and self.assemble) else None
+                       for _ in range(self.n_buf)]
         self.work = [None] * self.n_buf
         self.frame = None
         self.i = 0
@@ -87,7 +94,10 @@ class FramePipeline:
             self.work[b].wait()  # the current stream waits for the collective
             self.work[b] = None
             if self.rank == 0:
-                self.frame = assemble_frame(self.gathered[b], *self.dims).contiguous()
+                if self.assemble:
+                    self.frame = self.assemble[b % len(self.traces)](self.gathered[b], self.frames[b])
+                else:
+                    self.frame = assemble_frame(self.gathered[b], *self.dims).contiguous()
 
     def step(self):
         b = self.i % self.n_buf

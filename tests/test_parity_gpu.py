@@ -241,6 +241,36 @@ def test_scan_list_overflow_and_ragged_lengths(pkg, gpu, O):
         assert sorted(unsub.tolist()) == sorted(i for i in want_unsub if i < node_length)
 
 
+def test_assemble_tiles_kernel(pkg, gpu):
+    """svo_assemble_tiles (rank 0's un-permute after the gather) equals the torch expression the CPU tests use."""
+    import torch
+    for world, (W, H, tw, th) in ((1, (128, 64, 64, 8)), (3, (192, 40, 64, 8)), (8, (1920, 1080, 64, 8)), (5, (96, 48, 32, 16))):
+        n_pad = pkg.sharding.padded_tile_count(W, H, tw, th, world)
+        g = torch.randint(-2 ** 31, 2 ** 31 - 1, (world, n_pad, th * tw, 4), dtype=torch.int32, device="cuda")
+        render = pkg.Render(gpu, (W, H), np.array([0x80000000] * 8, dtype=np.uint32), capacity=64)
+        got = render.assemble_tiles(g, tw, th)
+        gpu.sync()
+        want = pkg.sharding.assemble_frame(g, W, H, tw, th).contiguous()
+        assert torch.equal(got, want), (world, W, H)
+    with pytest.raises(pkg.SvoError):
+        render.assemble_tiles(g[:1], tw, th)  # fewer tiles than the frame has
+
+
+def test_frame_pipeline_nccl_single_rank(pkg, gpu):
+    """bench.py's N > 1 loop (lanes on separate HIP streams, async RCCL gather, svo_assemble_tiles) with a one-rank
+    process group: every completed frame equals the directly rendered one.  (More ranks need more GPUs; the rank
+    arithmetic is covered over gloo in test_sharding_multiproc.py.)"""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_pipeline_world1.py")
+    r = subprocess.run([sys.executable, script, str(port)], capture_output=True, text=True, timeout=300)
+    assert "PIPELINE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_error_paths(pkg, gpu):
     """Call-order and argument errors come back as statuses, not aborts."""
     g = pkg.Gpu(0)
