@@ -53,6 +53,9 @@ def main():
                     help="consecutive frames rotate over this many HIP streams / device contexts, so the serial tail of one "
                          "frame's rays overlaps the next frames.  0 = default: 1 at N=1 (frames serial, which is what "
                          "roofline.* describes), 3 at N>1 (a rank's share of a sharded frame is too small to fill a GPU)")
+    ap.add_argument("--wire", default="packed12", choices=["packed12", "full16"],
+                    help="N>1: what the frame-end gather carries per ray: the 12-byte wire record (the fourth word of svo_hit "
+                         "repeats bits of the third; rank 0 rebuilds it while un-permuting) or the full 16-byte record")
     ap.add_argument("--cpu-frac", type=int, default=1, help="cpu_baseline traces the top 1/n of the frame's rows")
     a = ap.parse_args()
 
@@ -131,8 +134,9 @@ def main():
         if a.backend == "nccl":
             traces = [(lambda buf, r=r: r.render_tiles(tw, th, rank, world, hits=buf)) for _, r, _ in lanes]
             assemble = [(lambda g, out, r=r: r.assemble_tiles(g, tw, th, out=out)) for _, r, _ in lanes]
+            pack = [(lambda rec, wire, r=r: r.pack_records(rec, wire)) for _, r, _ in lanes] if a.wire == "packed12" else None
             pipe = pkg.sharding.FramePipeline(traces, W, H, tw, th, rank, world, f"cuda:{local_rank}",
-                                              streams=[s for _, _, s in lanes], assemble=assemble)
+                                              streams=[s for _, _, s in lanes], assemble=assemble, pack=pack)
         else:
             n_pad_v = pkg.sharding.padded_tile_count(W, H, tw, th, world)
 
@@ -145,7 +149,7 @@ def main():
                 return trace
 
             pipe = pkg.sharding.FramePipeline([via_host(r) for _, r, _ in lanes], W, H, tw, th, rank, world, "cpu",
-                                              streams=[s for _, _, s in lanes])
+                                              streams=[s for _, _, s in lanes], pack=True if a.wire == "packed12" else None)
         step = pipe.step
 
     def barrier():
@@ -192,7 +196,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
             "config": {"workload": a.workload, "width": W, "height": H, "octree_max_depth": wl["max_depth"],
                        "node_words": int(words.size), "node_bytes": int(words.size) * 4, "rays_per_step": n_rays,
-                       "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight, "backend": a.backend if world > 1 else None, "sharding": "none" if world == 1 else f"tiles {tw}x{th} round-robin, 1 RCCL gather per frame overlapped with the following frames' traces",
+                       "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight, "backend": a.backend if world > 1 else None, "sharding": "none" if world == 1 else f"tiles {tw}x{th} round-robin, 1 RCCL gather per frame ({12 if a.wire == 'packed12' else 16} B/ray) overlapped with the following frames' traces",
                        "scene_gen_s": round(gen_s, 1)},
         }
         cpu = None

@@ -162,6 +162,12 @@ int svo_render_tiles_secondary(svo_ctx *ctx, uint32_t width, uint32_t height, ui
  * layout svo_render_tiles writes); frame_out receives the row-major width x height frame.  Device pointers. */
 int svo_assemble_tiles(svo_ctx *ctx, const svo_hit *gathered, uint32_t world, uint32_t n_pad, uint32_t width,
                        uint32_t height, uint32_t tile_w, uint32_t tile_h, svo_hit *frame_out);
+/* The same with 12-byte wire records, and the packing that produces them: the fourth word of svo_hit (packed_normal)
+ * repeats bits 17..22 of the third, so a rank can send {voxel_index, t, steps_depth_hit} only -- a quarter fewer bytes
+ * on the links -- and rank 0 rebuilds full records while it un-permutes.  Device pointers. */
+int svo_pack_records(svo_ctx *ctx, const svo_hit *records, size_t n, uint32_t *wire_out);
+int svo_assemble_tiles_packed(svo_ctx *ctx, const uint32_t *gathered_wire, uint32_t world, uint32_t n_pad, uint32_t width,
+                              uint32_t height, uint32_t tile_w, uint32_t tile_h, svo_hit *frame_out);
 /* octree_ray over n explicit rays (6 floats each: pos.xyz, dir.xyz; device pointers). */
 int svo_trace_rays(svo_ctx *ctx, const float *rays, size_t n_rays, svo_hit *hits_out);
 

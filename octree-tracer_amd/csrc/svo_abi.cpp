@@ -672,8 +672,8 @@ int svo_render_tiles_secondary(svo_ctx *ctx, uint32_t width, uint32_t height, ui
     return trace_secondary(ctx, work, n_secondary, primary_out, secondary_out);
 }
 
-int svo_assemble_tiles(svo_ctx *ctx, const svo_hit *gathered, uint32_t world, uint32_t n_pad, uint32_t width, uint32_t height,
-                       uint32_t tile_w, uint32_t tile_h, svo_hit *frame_out) {
+static int assemble_common(svo_ctx *ctx, const void *gathered, bool packed, uint32_t world, uint32_t n_pad, uint32_t width,
+                           uint32_t height, uint32_t tile_w, uint32_t tile_h, svo_hit *frame_out) {
     if (!ctx || !gathered || !frame_out) return SVO_ERR_ARG;
     if (world == 0 || tile_w == 0 || tile_h == 0 || width % tile_w || height % tile_h)
         return fail(ctx, SVO_ERR_ARG, "frame must be a whole number of tiles");
@@ -682,7 +682,26 @@ int svo_assemble_tiles(svo_ctx *ctx, const svo_hit *gathered, uint32_t world, ui
     if ((uint64_t)width * height > (1u << 26)) return fail(ctx, SVO_ERR_ARG, "frame too large");
     int rc = bind(ctx);
     if (rc) return rc;
-    HIP_TRY(ctx, svo::launch_assemble_tiles(gathered, frame_out, world, n_pad, width, height, tile_w, tile_h, ctx->stream));
+    HIP_TRY(ctx, svo::launch_assemble_tiles(gathered, packed, frame_out, world, n_pad, width, height, tile_w, tile_h, ctx->stream));
+    return SVO_OK;
+}
+
+int svo_assemble_tiles(svo_ctx *ctx, const svo_hit *gathered, uint32_t world, uint32_t n_pad, uint32_t width, uint32_t height,
+                       uint32_t tile_w, uint32_t tile_h, svo_hit *frame_out) {
+    return assemble_common(ctx, gathered, false, world, n_pad, width, height, tile_w, tile_h, frame_out);
+}
+
+int svo_assemble_tiles_packed(svo_ctx *ctx, const uint32_t *gathered_wire, uint32_t world, uint32_t n_pad, uint32_t width,
+                              uint32_t height, uint32_t tile_w, uint32_t tile_h, svo_hit *frame_out) {
+    return assemble_common(ctx, gathered_wire, true, world, n_pad, width, height, tile_w, tile_h, frame_out);
+}
+
+int svo_pack_records(svo_ctx *ctx, const svo_hit *records, size_t n, uint32_t *wire_out) {
+    if (!ctx || ((!records || !wire_out) && n)) return SVO_ERR_ARG;
+    if (n > (1u << 26)) return fail(ctx, SVO_ERR_ARG, "too many records for one call");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, svo::launch_pack_records(records, wire_out, (uint32_t)n, ctx->stream));
     return SVO_OK;
 }
 

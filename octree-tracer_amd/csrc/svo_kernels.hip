@@ -1286,25 +1286,58 @@ hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cos
 }
 
 // Un-permute a gathered, tile-sharded frame (rank r, slot k holds tile r + k * world, row-major inside the tile) into
-// the row-major frame: one 16-byte record per thread, 64-pixel tile rows stay contiguous on both sides.
-__global__ __launch_bounds__(256) void assemble_tiles_kernel(const uint4 *gathered, uint4 *frame, uint32_t world, uint32_t n_pad,
+// the row-major frame: one 16-byte record per thread, 64-pixel tile rows stay contiguous on both sides.  PACKED: the
+// gathered records are the 12-byte wire form (pack_records_kernel); the fourth word is rebuilt from the third.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void assemble_tiles_kernel(const uint32_t *gathered, uint4 *frame, uint32_t world, uint32_t n_pad,
                                                              uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h) {
     const uint32_t tiles_x = width / tile_w, n = width * height;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const uint32_t y = i / width, x = i - y * width;
         const uint32_t ty = y / tile_h, tx = x / tile_w;
         const uint32_t t = ty * tiles_x + tx, r = t % world, k = t / world;
-        frame[i] = gathered[((uint64_t)r * n_pad + k) * (tile_w * tile_h) + (y - ty * tile_h) * tile_w + (x - tx * tile_w)];
+        const uint64_t src = ((uint64_t)r * n_pad + k) * (tile_w * tile_h) + (y - ty * tile_h) * tile_w + (x - tx * tile_w);
+        if (PACKED) {
+            const uint32_t *p = gathered + 3u * src;
+            const uint32_t info = p[2];
+            frame[i] = make_uint4(p[0], p[1], info, (info >> 17) & 63u);
+        } else {
+            frame[i] = reinterpret_cast<const uint4 *>(gathered)[src];
+        }
     }
 }
 
-hipError_t launch_assemble_tiles(const svo_hit *gathered, svo_hit *frame, uint32_t world, uint32_t n_pad, uint32_t width,
+// 16-byte records -> 12-byte wire records for the frame-end gather: the packed normal (word 3) is a copy of bits
+// 17..22 of word 2 (write_hit), so dropping it loses nothing and saves a quarter of the bytes on the links.
+__global__ __launch_bounds__(256) void pack_records_kernel(const uint4 *records, uint32_t *wire, uint32_t n) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint4 r = records[i];
+        wire[3u * i + 0u] = r.x;
+        wire[3u * i + 1u] = r.y;
+        wire[3u * i + 2u] = r.z;
+    }
+}
+
+hipError_t launch_assemble_tiles(const void *gathered, bool packed, svo_hit *frame, uint32_t world, uint32_t n_pad, uint32_t width,
                                  uint32_t height, uint32_t tile_w, uint32_t tile_h, hipStream_t stream) {
     (void)hipGetLastError();
     uint32_t blocks = (width * height + 255u) / 256u;
     if (blocks > 8192u) blocks = 8192u;
-    hipLaunchKernelGGL(assemble_tiles_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(gathered),
-                       reinterpret_cast<uint4 *>(frame), world, n_pad, width, height, tile_w, tile_h);
+    if (packed)
+        hipLaunchKernelGGL(assemble_tiles_kernel<true>, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint32_t *>(gathered),
+                           reinterpret_cast<uint4 *>(frame), world, n_pad, width, height, tile_w, tile_h);
+    else
+        hipLaunchKernelGGL(assemble_tiles_kernel<false>, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint32_t *>(gathered),
+                           reinterpret_cast<uint4 *>(frame), world, n_pad, width, height, tile_w, tile_h);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_records(const svo_hit *records, uint32_t *wire, uint32_t n, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n == 0) return hipSuccess;
+    uint32_t blocks = (n + 255u) / 256u;
+    if (blocks > 8192u) blocks = 8192u;
+    hipLaunchKernelGGL(pack_records_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(records), wire, n);
     return hipGetLastError();
 }
 

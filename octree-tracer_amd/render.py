@@ -156,15 +156,22 @@ class Render:
         return hits, secondary
 
     def assemble_tiles(self, gathered, tile_w, tile_h, out=None):
-        """Rank 0: un-permute a gathered frame ([world, n_pad, tile_h * tile_w, 4] int32, device) into the row-major frame
+        """Rank 0: un-permute a gathered frame ([world, n_pad, tile_h * tile_w, 4] int32, device; last dimension 3 for wire
+        records) into the row-major frame
         ([H, W, 4]) with one kernel on this context's stream (svo_assemble_tiles)."""
         w, h = self.size
         world, n_pad = int(gathered.shape[0]), int(gathered.shape[1])
         if out is None:
             out = torch.empty((h, w, 4), dtype=torch.int32, device=gathered.device)
-        self.gpu.check(lib().svo_assemble_tiles(self.gpu._h, gathered.data_ptr(), world, n_pad, w, h, tile_w, tile_h,
-                                                out.data_ptr()))
+        fn = lib().svo_assemble_tiles_packed if gathered.shape[-1] == 3 else lib().svo_assemble_tiles
+        self.gpu.check(fn(self.gpu._h, gathered.data_ptr(), world, n_pad, w, h, tile_w, tile_h, out.data_ptr()))
         return out
+
+    def pack_records(self, records, wire):
+        """[..., 4] int32 hit records -> [..., 3] int32 wire records (svo_pack_records), on this context's stream."""
+        n = records.numel() // 4
+        self.gpu.check(lib().svo_pack_records(self.gpu._h, records.data_ptr(), n, wire.data_ptr()))
+        return wire
 
     def render_host(self, tile=None, rgba=False):
         """Blocking variant with host results: hit records (numpy structured array, tile-local row-major)

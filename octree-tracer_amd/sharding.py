@@ -35,8 +35,21 @@ def gather_frame(local, rank, world, dst=0, group=None):
     return None
 
 
+def pack_records(records):
+    """[..., 4] hit records -> [..., 3] wire records: word 3 (packed_normal) repeats bits 17..22 of word 2."""
+    return records[..., :3].contiguous()
+
+
+def unpack_records(wire):
+    """inverse of pack_records"""
+    return torch.cat([wire, ((wire[..., 2:3] >> 17) & 63)], dim=-1)
+
+
 def assemble_frame(gathered, width, height, tile_w, tile_h):
-    """[world, n_pad, tile_h*tile_w, 4] (rank r, slot k holds tile r + k*world) -> [H, W, 4]."""
+    """[world, n_pad, tile_h*tile_w, 4] (rank r, slot k holds tile r + k*world) -> [H, W, 4].  Wire records
+    (last dimension 3) are expanded on the way."""
+    if gathered.shape[-1] == 3:
+        gathered = unpack_records(gathered)
     world, n_pad = gathered.shape[0], gathered.shape[1]
     tiles_x, tiles_y = width // tile_w, height // tile_h
     n = tiles_x * tiles_y
@@ -61,12 +74,16 @@ class FramePipeline:
     other ranks; with `assemble` it lives in a buffer that is reused after as many further steps as there are
     buffers); drain() completes what is in flight and returns the last frame."""
 
-    def __init__(self, trace, width, height, tile_w, tile_h, rank, world, device, group=None, streams=None, assemble=None):
+    def __init__(self, trace, width, height, tile_w, tile_h, rank, world, device, group=None, streams=None, assemble=None,
+                 pack=None):
         """assemble (optional, rank 0): one callable per lane, `assemble(gathered, out) -> out`, that un-permutes a gathered
         frame on the lane's stream (Render.assemble_tiles: one kernel, a few microseconds of host time); without it the
         generic torch expression assemble_frame() is used."""
         self.traces = list(trace) if isinstance(trace, (list, tuple)) else [trace]
         self.assemble = list(assemble) if assemble is not None else None
+        # pack: what goes over the links is the 12-byte wire form of the records.  True = the torch expression
+        # pack_records(); a list = one callable per lane, `pack(records, wire) -> wire` (Render.pack_records)
+        self.pack = pack
         self.streams = list(streams) if streams is not None else None
         if self.streams is not None and len(self.streams) != len(self.traces):
             raise ValueError("one stream per lane")
@@ -75,7 +92,10 @@ class FramePipeline:
         self.n_buf = max(2, len(self.traces))  # a lone lane is still double-buffered against its gather
         n_pad = padded_tile_count(width, height, tile_w, tile_h, world)
         self.local = [torch.zeros((n_pad, tile_h * tile_w, 4), dtype=torch.int32, device=device) for _ in range(self.n_buf)]
-        self.gathered = [torch.empty((world, n_pad, tile_h * tile_w, 4), dtype=torch.int32, device=device)
+        words = 3 if pack else 4
+        self.wire = [torch.zeros((n_pad, tile_h * tile_w, 3), dtype=torch.int32, device=device) if pack else None
+                     for _ in range(self.n_buf)]
+        self.gathered = [torch.empty((world, n_pad, tile_h * tile_w, words), dtype=torch.int32, device=device)
                          if rank == 0 else None for _ in range(self.n_buf)]
         self.frames = [torch.empty((height, width, 4), dtype=torch.int32, device=device) if (rank == 0 and self.assemble) else None
                        for _ in range(self.n_buf)]
@@ -103,12 +123,19 @@ class FramePipeline:
         b = self.i % self.n_buf
         with self._on_lane(b):
             self._finish(b)      # buffer b is free again once the frame that used it has been gathered
-            self.traces[b % len(self.traces)](self.local[b])
+            lane = b % len(self.traces)
+            self.traces[lane](self.local[b])
+            send = self.local[b]
+            if self.pack:
+                if self.pack is True:
+                    self.wire[b].copy_(pack_records(self.local[b]))
+                else:
+                    self.pack[lane](self.local[b], self.wire[b])
+                send = self.wire[b]
             if self.rank == 0:
-                self.work[b] = dist.gather(self.local[b], list(self.gathered[b].unbind(0)), dst=0, group=self.group,
-                                           async_op=True)
+                self.work[b] = dist.gather(send, list(self.gathered[b].unbind(0)), dst=0, group=self.group, async_op=True)
             else:
-                self.work[b] = dist.gather(self.local[b], None, dst=0, group=self.group, async_op=True)
+                self.work[b] = dist.gather(send, None, dst=0, group=self.group, async_op=True)
         self.i += 1
         return self.frame
 

@@ -33,16 +33,19 @@ def main():
         lanes.append((g, pkg.Render.share_nodes(g, render), s))
     traces = [(lambda buf, r=r: r.render_tiles(tw, th, 0, 1, hits=buf)) for _, r, _ in lanes]
     assemble = [(lambda g_, out, r=r: r.assemble_tiles(g_, tw, th, out=out)) for _, r, _ in lanes]
-    pipe = pkg.sharding.FramePipeline(traces, W, H, tw, th, 0, 1, "cuda:0", streams=[s for _, _, s in lanes], assemble=assemble)
+    pack = [(lambda rec, wire, r=r: r.pack_records(rec, wire)) for _, r, _ in lanes]
     ok = True
-    for k in range(8):
-        frame = pipe.step()
-        if frame is not None:
-            torch.cuda.synchronize()
-            ok = ok and bool(np.array_equal(frame.cpu().numpy().view(np.uint32), want))
-    last = pipe.drain()
-    torch.cuda.synchronize()
-    ok = ok and bool(np.array_equal(last.cpu().numpy().view(np.uint32), want))
+    for packers in (pack, None):  # 12-byte wire records (bench.py's default) and full records
+        pipe = pkg.sharding.FramePipeline(traces, W, H, tw, th, 0, 1, "cuda:0", streams=[s for _, _, s in lanes],
+                                          assemble=assemble, pack=packers)
+        for k in range(8):
+            frame = pipe.step()
+            if frame is not None:
+                torch.cuda.synchronize()
+                ok = ok and bool(np.array_equal(frame.cpu().numpy().view(np.uint32), want))
+        last = pipe.drain()
+        torch.cuda.synchronize()
+        ok = ok and bool(np.array_equal(last.cpu().numpy().view(np.uint32), want))
     dist.barrier()
     dist.destroy_process_group()
     print("PIPELINE_OK" if ok else "PIPELINE_MISMATCH")

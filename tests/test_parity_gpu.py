@@ -252,6 +252,14 @@ def test_assemble_tiles_kernel(pkg, gpu):
         gpu.sync()
         want = pkg.sharding.assemble_frame(g, W, H, tw, th).contiguous()
         assert torch.equal(got, want), (world, W, H)
+        # 12-byte wire records: pack kernel == torch expression, packed assemble rebuilds word 3 from word 2
+        wire = render.pack_records(g, torch.empty((world, n_pad, th * tw, 3), dtype=torch.int32, device="cuda"))
+        gpu.sync()
+        assert torch.equal(wire, pkg.sharding.pack_records(g))
+        got = render.assemble_tiles(wire, tw, th)
+        gpu.sync()
+        want = pkg.sharding.assemble_frame(wire, W, H, tw, th).contiguous()
+        assert torch.equal(got, want) and torch.equal(got[..., 3], (got[..., 2] >> 17) & 63)
     with pytest.raises(pkg.SvoError):
         render.assemble_tiles(g[:1], tw, th)  # fewer tiles than the frame has
 

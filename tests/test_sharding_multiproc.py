@@ -74,19 +74,25 @@ def _worker(rank, world, port, W, H, tw, th, out_path):
             def trace(buf):
                 count[0] += 1
                 seen[lane].append(count[0])
-                buf.copy_(local + 100 * count[0])
+                buf.copy_(local)
+                buf[..., 0] += 100 * count[0]  # frame k is marked in the voxel-index word (words 2 and 3 stay consistent:
+                return None                     # the 12-byte wire form rebuilds word 3 from word 2)
             return trace
 
-        pipe = sh.FramePipeline([lane_trace(k) for k in range(3)], W, H, tw, th, rank, world, "cpu")
+        pipe = sh.FramePipeline([lane_trace(k) for k in range(3)], W, H, tw, th, rank, world, "cpu", pack=True)
         done = [pipe.step() for k in range(7)]
         last = pipe.drain()
         ok = ok and seen == [[1, 4, 7], [2, 5], [3, 6]]
         if rank == 0:
+            def marked(n):
+                m = want.copy()
+                m[..., 0] += np.uint32(100 * n)
+                return m
             # step k (0-based) first frees its buffer: the frame that used it, k - 3, is complete by then
             for k in range(3, 7):
-                ok = ok and bool(np.array_equal(done[k].numpy().view(np.uint32), want + np.uint32(100 * (k - 2))))
+                ok = ok and bool(np.array_equal(done[k].numpy().view(np.uint32), marked(k - 2)))
             ok = ok and done[2] is None
-            ok = ok and bool(np.array_equal(last.numpy().view(np.uint32), want + np.uint32(700)))
+            ok = ok and bool(np.array_equal(last.numpy().view(np.uint32), marked(7)))
             np.save(out_path, np.array([int(ok)]))
     finally:
         dist.destroy_process_group()
