@@ -526,6 +526,10 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
         return c;
     };
     Cursor cur = claim(Cursor{0u, 0u, wave_id, 0u}, true);
+    // A claim on the home list is issued as soon as a strip has been turned into pool rays, but its answer is only
+    // looked at when the pool is empty again: the atomic's round trip overlaps the traversal instead of stalling the wave.
+    uint32_t pend = 0;      // lane 0: what the atomic returned
+    bool pending = false;   // wave-uniform
     uint32_t next = cur.next, strip_end = cur.end;
     uint32_t pool_n = 0, pool_i = 0;  // wave-uniform: rays waiting in the pool, index of the first
     // optional per-wave timeline (diagnostic builds of the host set a.debug): start, queue-dry, end in 10 ns ticks
@@ -582,6 +586,28 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
         uint64_t act = __ballot((int32_t)st < 0);  // ST_ACTIVE is the sign bit: one compare
         const uint32_t n_idle = 64u - (uint32_t)__popcll(act);
         if (n_idle >= a.refill_min) {
+            if (pending && pool_n == 0u) {  // now the answer of the early claim is needed
+                pending = false;
+                const uint32_t sh = blockIdx.x % kShards;
+                const uint32_t k = __builtin_amdgcn_readfirstlane(pend) + ((gridDim.x + kShards - 1u - sh) / kShards) * (uint32_t)(BLOCK / 64);
+                uint32_t s = 0xFFFFFFFFu;
+                if (order) {
+                    if (k < order[sh]) s = order[kShards + sh * a.order_cap + k];
+                } else {
+                    const uint32_t cand = sh * per_shard + k;
+                    if (k < per_shard && cand < n_strips) s = cand;
+                }
+                if (s != 0xFFFFFFFFu) {
+                    next = __builtin_amdgcn_readfirstlane(s) * strip_items;
+                    strip_end = min(next + strip_items, n_items);
+                } else {  // the home list is exhausted: go on with the other lists, synchronously
+                    cur.shard_try = 1u;
+                    cur = claim(cur, false);
+                    next = cur.next;
+                    strip_end = cur.end;
+                }
+                if (DBG && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
+            }
             const bool more = (pool_n != 0u) || (next != 0xFFFFFFFFu);
             if (more) {
                 if (DBG) dbg_refills += 1;
@@ -644,9 +670,15 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                     pool_i = 0u;
                     next += min(64u, strip_end - next);
                     if (next >= strip_end) {
-                        cur = claim(cur, false);
-                        next = cur.next;
-                        strip_end = cur.end;
+                        if (work_counter && cur.shard_try == 0u) {
+                            if (lane == 0) pend = atomicAdd(work_counter + (blockIdx.x % kShards) * kShardStride, 1u);
+                            pending = true;
+                            next = strip_end = 0xFFFFFFFEu;  // not known yet (and not "dry")
+                        } else {
+                            cur = claim(cur, false);
+                            next = cur.next;
+                            strip_end = cur.end;
+                        }
                     }
                     if (DBG && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
                 }
