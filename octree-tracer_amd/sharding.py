@@ -67,8 +67,8 @@ class FramePipeline:
     torch.cuda.Stream per lane): consecutive frames then go to different HIP streams (each lane drives its own
     device context), so the serial tail of one frame's rays overlaps the next frames.  A rank's share of a
     sharded frame is small, and a ray is a serial chain of up to 101 dependent rounds: with one frame at a
-    time the GPU idles through every frame's tail (tools/pipeline_probe.py: 1/8 of a 1080p frame takes 0.18 ms
-    alone and 0.085 ms with three frames in flight).
+    time the GPU idles through every frame's tail (tools/pipeline_probe.py: 1/8 of a 1080p frame takes 0.16 ms
+    alone and 0.076 ms with three frames in flight).
 
     step() returns the most recent COMPLETED frame on rank 0 (None until the first one is ready, and on
     other ranks; with `assemble` it lives in a buffer that is reused after as many further steps as there are
