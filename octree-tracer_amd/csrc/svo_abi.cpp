@@ -37,7 +37,7 @@ struct svo_ctx {
     // options
     int variant = SVO_VARIANT_STACK;
     int grid_blocks = 0;
-    uint32_t refill_min = 12;
+    uint32_t refill_min = 16;
     bool scan_clears = false;
     void *scatter_buf = nullptr;
     size_t scatter_bytes = 0;
