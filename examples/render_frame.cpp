@@ -59,13 +59,17 @@ int main(int argc, char **argv) {
         // the streaming loop of App::update (app.rs:94-118) over the world: the device tree grows from the root group
         svo::Octree streamed = world.root_octree();
         size_t subdivided = 0;
+        render.write_nodes(streamed.raw_data(), streamed.len());
+        streamed.take_dirty();
+        gpu.set_option(SVO_OPT_SCAN_CLEARS_COUNTERS, 1);  // the scan resets the counters, so only changed words are re-sent
         for (int frame = 0; frame < 8; frame++) {
-            render.write_nodes(streamed.raw_data(), streamed.len());
             render.render_host(hits.data());
             compute.update(streamed);
             auto l = compute.read_lists();
             subdivided += world.process_subdivision(l.first, streamed);
             world.process_unsubdivision(l.second, streamed);
+            auto dirty = streamed.take_dirty();
+            render.scatter_nodes(dirty.first, dirty.second);
         }
         std::printf("streaming: %zu subdivisions, device tree %zu words\n", subdivided, streamed.len());
         return n_hit > 0 && subdivided > 0 ? 0 : 2;

@@ -130,6 +130,13 @@ class Octree {  // octree.rs:43-162
         if (rc < 0) throw Error(SVO_ERR_STATE, "Tried to unsubdivide a node without position!");
         return rc == 0;
     }
+    // words written since the previous call (index, value), each index once: the input of Render::scatter_nodes
+    std::pair<std::vector<uint32_t>, std::vector<uint32_t>> take_dirty() {
+        const size_t n = svo_octree_take_dirty(o_, nullptr, nullptr, 0);
+        std::vector<uint32_t> idx(n), val(n);
+        if (n) svo_octree_take_dirty(o_, idx.data(), val.data(), n);
+        return {std::move(idx), std::move(val)};
+    }
     svo_octree *raw() const { return o_; }
 
   private:
@@ -219,6 +226,12 @@ class Render {  // render.rs:3-285
         : Render(gpu, w, h, octree.raw_data(), octree.len(), capacity) {}
     // queue.write_buffer(&node_buffer, 0, nodes) (app.rs:113-118)
     void write_nodes(const uint32_t *words, size_t n) { gpu_.check(svo_nodes_write(gpu_.ctx(), 0, words, n)); }
+    // incremental form of the same upload: only the words that changed (svo_nodes_scatter; pair it with
+    // gpu.set_option(SVO_OPT_SCAN_CLEARS_COUNTERS, 1), which takes over the counter reset of the full upload)
+    void scatter_nodes(const std::vector<uint32_t> &indices, const std::vector<uint32_t> &words) {
+        gpu_.check(svo_nodes_scatter(gpu_.ctx(), indices.data(), words.data(), indices.size()));
+        gpu_.poll_wait();  // the vectors may go away
+    }
     // Render::resize ignores zero sizes (render.rs:182-189)
     void resize(uint32_t w, uint32_t h) {
         if (w > 0 && h > 0) { width = w; height = h; }
