@@ -135,7 +135,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     const bool counting = (work.mode != 2 || opt.count_rays) && !(ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE);
     a.count_nodes = counting ? ctx->nodes : nullptr;
     const bool debug_hits = (ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE) && (ctx->uniforms.flags & SVO_F_SHOW_HITS);
-    const bool stack = ctx->variant == SVO_VARIANT_STACK && !counting && !debug_hits;
+    const bool stack = ctx->variant == SVO_VARIANT_STACK && !debug_hits;
     const uint32_t n_strips = (wd.n_items + 63u) / 64u;
     const bool schedule = ctx->schedule && n_strips <= svo::kMaxScheduledStrips;
     svo_ctx::Sched &sc = ctx->sched[opt.sched_slot & 1];
@@ -388,7 +388,7 @@ int svo_ctx_create(int hip_device, svo_ctx **out) {
         ctx->num_cus = prop.multiProcessorCount;
         e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     }
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->top_table, svo::kTopEntries * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->top_table, (svo::kTopEntries + svo::kTopAuxEntries) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->status, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(ctx->status, 0, sizeof(uint32_t));
     if (e != hipSuccess) {

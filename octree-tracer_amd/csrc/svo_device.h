@@ -12,6 +12,7 @@ constexpr uint32_t kVoxelOffset = 134217728u;  // octree.rs:5
 constexpr uint32_t kMaxDescent = 31;           // descent guard (see oracle/svo_oracle.c)
 constexpr int kTopLevels = 3;                  // K: octree levels folded into the LDS top table
 constexpr int kTopEntries = 1 << (3 * kTopLevels);
+constexpr int kTopAuxEntries = 8 + 64;  // level-1 and level-2 cells -> child group of the next level (kTopLevels = 3)
 constexpr int kPathBits = 24;                  // D: integer path-code bits per axis
 constexpr int kCounterWords = 256;             // 8 claim counters, one per 128-byte line
 

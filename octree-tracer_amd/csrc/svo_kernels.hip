@@ -320,6 +320,24 @@ __global__ __launch_bounds__(256) void build_top_table_kernel(const uint32_t *no
         entry = (((uint32_t)top_levels + 1u) << 27) | (tn & 0x07FFFFFFu);
     }
     table[cell] = entry;
+    // Behind the table: for every level-k cell (k = 1 .. K-1) the child group to read at level k+1, or all ones below a
+    // leaf.  Only the hit-counting instantiation of the STACK kernel uses them: it needs the address of EVERY word on a
+    // ray's path, also above the levels the table skips.
+    uint32_t at = (uint32_t)kTopEntries;
+    for (int k = 1; k < top_levels; k++) {
+        if (cell < (1u << (3 * k))) {
+            const uint32_t kx = (cell >> (2 * k)) & ((1u << k) - 1u), ky = (cell >> k) & ((1u << k) - 1u), kz = cell & ((1u << k) - 1u);
+            uint32_t g = 0;
+            for (int lvl = 1; lvl <= k && g != 0xFFFFFFFFu; lvl++) {
+                const int sh = k - lvl;
+                const uint32_t child = (((kx >> sh) & 1u) << 2) | (((ky >> sh) & 1u) << 1) | ((kz >> sh) & 1u);
+                const uint32_t tn = load_word(rs, g + child) >> 4;
+                g = tn >= kVoxelOffset ? 0xFFFFFFFFu : tn;
+            }
+            table[at + cell] = g;
+        }
+        at += 1u << (3 * k);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -427,7 +445,7 @@ __device__ __forceinline__ bool clean_component(float p, float d) {
 
 // Per-lane state word: bits 0..7 steps | 8..12 leaf depth L | 13..15 step mask (axes of the last step's
 // normal) | 16 normal-is-entry-normal | 31 active | 30 needs descent (only ever set together with active) | 21 record pending | 22..24 how it ended
-constexpr uint32_t ST_L_SHIFT = 8, ST_M_SHIFT = 13;
+constexpr uint32_t ST_L_SHIFT = 8, ST_M_SHIFT = 13, ST_SAT_SHIFT = 25;  // bits 25..29: see step 3a (counting instantiation)
 constexpr uint32_t ST_ENTRY = 1u << 16, ST_ACTIVE = 1u << 31, ST_DESC = 1u << 30;
 // a finished ray keeps its state until the lane is refilled: record not yet written + how it ended
 constexpr uint32_t ST_PENDING = 1u << 21, ST_F_TOODEEP = 1u << 22, ST_F_SOLID = 1u << 23, ST_F_INB = 1u << 24;
@@ -446,8 +464,9 @@ constexpr int kPoolWords = 11;
 // scale).  Scaling by a power of two commutes with every IEEE rounding involved (no overflow/underflow on
 // a clean ray), so  A = (C - P) + H,  t = A / Dr,  G = (P + Dr * t) +- K  are exactly 2^23 times the
 // reference's  a,  the same t,  and  2^23 * voxel_pos  -- and G is what the path codes need.
-template <int BLOCK, int NS, int K, bool GE, bool DBG>
-__global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
+// CNT: hit counters live (adaptive mode, shader.wgsl:157-161), see step 3a in the loop.
+template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT>
+__global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
@@ -459,6 +478,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
     uint32_t *tbl = lds;                          // TBL entries
     uint32_t *stk = lds + TBL;                    // [NS][BLOCK]
     uint32_t *pool_all = stk + (NS + 1) * BLOCK;  // [BLOCK / 64][kPoolWords][64] (one spare stack row, see the descent)
+    uint32_t *aux = pool_all + (BLOCK / 64) * (kPoolWords * 64);  // CNT: level-1 / level-2 cell -> child group (kTopAuxEntries)
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -466,6 +486,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
     const rsrc_t rs = make_rsrc(a.nodes, a.n_words);
 
     for (uint32_t i = tid; i < (uint32_t)TBL; i += BLOCK) tbl[i] = a.top_table[i];
+    if (CNT && tid < (uint32_t)kTopAuxEntries) aux[tid] = a.top_table[(uint32_t)TBL + tid];
     __syncthreads();
 
     const uint32_t n_items = a.work.n_items;
@@ -767,6 +788,32 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
         // ---- 3. hit test / DDA step (shader.wgsl:215-244), clean rays, grid units ----
         if ((int32_t)st < 0) {  // ST_ACTIVE
             const uint32_t L = (st >> ST_L_SHIFT) & 31u;
+            if (CNT) {
+                // ---- 3a. hit counters.  The reference's find_voxel bumps every word from the root to the leaf, once per
+                // call, i.e. once per round here (shader.wgsl:157-161); this kernel does not walk those words, but it
+                // knows their addresses: child group of level l (the top tables up to level K+1, the lane's stack below)
+                // + child index from the path codes.  A counter stops at 15, and near the root that happens within the
+                // first rounds of a frame, so each lane remembers up to which level the words of its current path are
+                // known to be saturated (ST_SAT; a restart at level r keeps that knowledge for levels < r) and only
+                // looks at the levels below.  Final counters = min(15, old + visits), like the RESTART kernel.
+                uint32_t sat = (st >> ST_SAT_SHIFT) & 31u;
+                for (uint32_t l = sat + 1u; l <= L; l++) {  // (per lane; typically the last two or three levels)
+                    const uint32_t kk = l - 1u, shc = (uint32_t)D - kk;
+                    uint32_t g = 0u;
+                    if (l >= (uint32_t)SBASE) {
+                        g = lds[(uint32_t)TBL + (l - (uint32_t)SBASE) * BLOCK + tid];
+                    } else if (kk != 0u) {
+                        const uint32_t cell = (((uint32_t)ix >> shc) << (2u * kk)) | (((uint32_t)iy >> shc) << kk) | ((uint32_t)iz >> shc);
+                        g = kk == (uint32_t)K ? (tbl[cell] & 0x07FFFFFFu) : aux[(kk == 1u ? 0u : 8u) + cell];
+                    }
+                    const uint32_t bit = (uint32_t)D - l;
+                    const uint32_t p = g + ((((uint32_t)ix >> bit) & 1u) << 2 | (((uint32_t)iy >> bit) & 1u) << 1 | (((uint32_t)iz >> bit) & 1u));
+                    const uint32_t word = l == L ? leaf_w : load_word(rs, p);
+                    if ((word & 15u) == 15u && l == sat + 1u) sat = l;
+                    count_visit(a.count_nodes, a.n_words, p, word);
+                }
+                st = (st & ~(31u << ST_SAT_SHIFT)) | (sat << ST_SAT_SHIFT);
+            }
             const bool too_deep = leaf_w < (kVoxelOffset << 4);  // descent stopped on an interior word
             const bool solid = (leaf_w >> 4) != kVoxelOffset;
             // leaf centre in grid units straight from the path code: keep the top L bits, set the next one
@@ -827,7 +874,12 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                 const uint32_t c = (uint32_t)__clz((int)((diff << 8) | 0x80u));
                 ix = jx; iy = jy; iz = jz;
                 st |= ST_DESC;
-                restart_at(min(min(c + 1u, L), (uint32_t)SMAX));
+                const uint32_t r = min(min(c + 1u, L), (uint32_t)SMAX);
+                if (CNT) {  // levels r and below belong to a new path
+                    const uint32_t sat = min((st >> ST_SAT_SHIFT) & 31u, r - 1u);
+                    st = (st & ~(31u << ST_SAT_SHIFT)) | (sat << ST_SAT_SHIFT);
+                }
+                restart_at(r);
             }
         }
     }
@@ -1262,10 +1314,13 @@ int stack_max_depth(bool deep) { return kTopLevels + 1 + (deep ? kStackLevelsDee
 template <bool GE, int NS>
 static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
     const uint32_t strip_items = args.order ? 64u : (li.strip_items ? li.strip_items : 64u);
-    auto kern = args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true> : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false>;
-    size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64) *
-                       sizeof(uint32_t);
-    static int blocks_per_cu = 0;
+    auto kern = args.count_nodes ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true>
+                                 : (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false>
+                                               : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false>);
+    size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
+                                (args.count_nodes ? kTopAuxEntries : 0)) * sizeof(uint32_t);
+    static int occupancy[2] = {0, 0};  // [counting instantiation?]
+    int &blocks_per_cu = occupancy[args.count_nodes ? 1 : 0];
     if (blocks_per_cu == 0) {
         int n = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kStackBlock, lds_bytes);
@@ -1286,9 +1341,8 @@ hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t
     (void)hipGetLastError();
     if (args.work.n_items == 0) return hipSuccess;
     const bool counter_hits = (args.u.flags & SVO_F_PAUSE_ADAPTIVE) && (args.u.flags & SVO_F_SHOW_HITS);
-    // the debug hit test reads counter bits, and the adaptive mode writes them for every level of every descent:
-    // both need the reference-shaped walk
-    if (li.variant == SVO_VARIANT_RESTART || counter_hits || args.count_nodes) {
+    // the debug hit test reads counter bits: it needs the reference-shaped walk
+    if (li.variant == SVO_VARIANT_RESTART || counter_hits) {
         uint32_t blocks = (args.work.n_items + 255u) / 256u;
         uint32_t cap = (uint32_t)li.num_cus * 8u;
         if (li.grid_blocks > 0) cap = (uint32_t)li.grid_blocks;

@@ -297,10 +297,13 @@ def test_error_paths(pkg, gpu):
     g.close()
 
 
-def test_hit_counters_adaptive_mode(pkg, gpu, O, small_words, monu9_words):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_hit_counters_adaptive_mode(pkg, gpu, O, small_words, monu9_words, variant):
     """pause_adaptive off: every word a primary ray's descent visits gets +1, saturating at 15
-    (shader.wgsl:157-161); the device words after a frame equal the oracle's order-independent count."""
-    for words, size in ((small_words, (96, 64)), (monu9_words, (160, 90))):
+    (shader.wgsl:157-161); the device words after a frame equal the oracle's order-independent count.  Both kernels:
+    RESTART walks those words, STACK reconstructs their addresses from its tables and stack."""
+    gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+    for words, size in ((small_words, (96, 64)), (monu9_words, (160, 90)), (monu9_words, (640, 360))):
         u = O.make_uniforms(width=size[0], height=size[1], flags=0)  # adaptive on, shadows off
         render = pkg.Render(gpu, size, words, capacity=words.size + 64)
         set_uniforms_from_oracle(render, u)
@@ -324,6 +327,33 @@ def test_hit_counters_adaptive_mode(pkg, gpu, O, small_words, monu9_words):
         assert sorted(sub.tolist()) == osub[1:1 + osub[0]].tolist()
         assert sorted(unsub.tolist()) == ounsub[1:1 + ounsub[0]].tolist()
         assert osub[0] > 0 or words.size > 1000  # (monu9 leaves are too small to collect 4 visits at this size)
+
+
+def test_hit_counters_large_tree_both_stacks(pkg, gpu, O):
+    """Counting on the ancestor stack at scale: a depth-14 terrain (camera inside, long rays, deep restarts) and a
+    depth-18 fractal through the deep-stack instantiation; counters after two frames equal the oracle's, records too."""
+    cam, look = pkg.scenes.terrain_camera(0, 14)
+    cases = [(pkg.scenes.terrain(seed=0, max_depth=14, cam=cam, lod_c=400.0, max_words=6_000_000), cam, look, 14),
+             (pkg.scenes.fractal(seed=1, max_depth=18, cam=(-0.999, -0.999, -0.999), lod_c=300.0, min_depth=4, max_words=4_000_000),
+              (-0.9990, -0.9985, -0.9980), (-1.0, -1.2, -0.9), 18)]
+    gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+    try:
+        for words, pos, lookv, depth in cases:
+            gpu.set_option(pkg.gpu.OPT_TREE_DEPTH, depth)
+            u = O.make_uniforms(pos=pos, look=lookv, width=320, height=180, flags=0)  # adaptive on, shadows off
+            render = pkg.Render(gpu, (320, 180), words, capacity=words.size)
+            set_uniforms_from_oracle(render, u)
+            want = words
+            for frame in range(2):
+                hits = pkg.render.hits_to_numpy(render.render())
+                gpu.sync()
+                assert_hits_equal(hits, O.trace_frame(words, u, threads=8), f"depth {depth} frame {frame}")
+                want = O.count_frame(want, u)
+                got = render.read_nodes(words.size)
+                assert np.array_equal(got, want), f"depth {depth} frame {frame}: {np.count_nonzero(got != want)} counters differ"
+            assert (want & 15).max() == 15 and np.count_nonzero(want & 15) > 1000
+    finally:
+        gpu.set_option(pkg.gpu.OPT_TREE_DEPTH, 16)
 
 
 def test_debug_show_hits_mode(pkg, gpu, O, small_words):
@@ -372,8 +402,10 @@ def test_shaded_frame(pkg, gpu, O, monu9_words, small_words, variant):
         assert img[..., :3].any()
 
 
-def test_shaded_frame_counts_shadow_rays(pkg, gpu, O, small_words):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_shaded_frame_counts_shadow_rays(pkg, gpu, O, small_words, variant):
     """Adaptive mode + shadows: the shadow ray passes primary = true (shader.wgsl:276), so it bumps counters too."""
+    gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
     u = O.make_uniforms(width=80, height=48, flags=O.F_SHADOWS)
     render = pkg.Render(gpu, (80, 48), small_words, capacity=small_words.size)
     set_uniforms_from_oracle(render, u)
