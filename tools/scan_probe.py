@@ -46,3 +46,13 @@ for name, fn in (("full re-upload (svo_nodes_write, 428 MB)", lambda: render.wri
         t0 = time.perf_counter(); fn(); gpu.sync(); ts.append(time.perf_counter() - t0)
     print(f"{name}: {np.median(ts) * 1e3:.2f} ms", flush=True)
 assert (render.read_nodes(words.size) & 15 == 0).all()
+
+# steady-state adaptive frames (counters reset by the scan every frame, schedule from the previous frame)
+ts = []
+for _ in range(12):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); render.render(); e1.record()
+    compute.update(int(words.size)); e1.synchronize()
+    ts.append(e0.elapsed_time(e1))
+    compute.read_lists()
+print(f"adaptive trace, steady state: {np.median(ts[2:]):.3f} ms per 1080p frame", flush=True)
