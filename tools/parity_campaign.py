@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--w", type=int, default=640)
     ap.add_argument("--h", type=int, default=360)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--count", action="store_true", help="adaptive mode: also compare the hit counters after each frame (slower: the oracle counts on one thread)")
     a = ap.parse_args()
     pkg, O = entry.load_package(), entry.load_oracle()
     gpu = pkg.Gpu(0)
@@ -51,19 +52,24 @@ def main():
             lookv = target - pos
             if np.linalg.norm(lookv) < 1e-3 or abs(lookv[0]) + abs(lookv[2]) < 1e-4:
                 lookv = np.array([0.3, -0.2, 0.9])
-            flags = O.F_PAUSE_ADAPTIVE | (O.F_MISC_BOOL if (k // 4) % 2 else 0)
+            flags = (0 if a.count else O.F_PAUSE_ADAPTIVE) | (O.F_MISC_BOOL if (k // 4) % 2 else 0)
             u = O.make_uniforms(pos=tuple(float(x) for x in pos), look=tuple(float(x) for x in lookv), fov=float(rng.choice([60, 90, 120])),
                                 width=a.w, height=a.h, flags=flags)
             for f in ("camera", "camera_inverse", "dimensions", "sun_dir"):
                 getattr(render.uniforms, f)[:] = list(getattr(u, f))
             render.uniforms.flags, render.uniforms.misc_value = u.flags, u.misc_value
             render.upload_uniforms()
+            if a.count:
+                render.write_nodes(words)  # counters back to zero
             buf = render.alloc_hits(a.w * a.h)
             buf.fill_(-1)
             got = pkg.render.hits_to_numpy(render.render(hits=buf)).view(np.uint32)
             gpu.sync()
             want = O.trace_frame(words, u, threads=threads).reshape(-1).view(np.uint32)
             total += 1
+            if a.count and not np.array_equal(render.read_nodes(words.size), O.count_frame(words, u)):
+                bad += 1
+                print(f"COUNTER MISMATCH scene {name} pose {k} pos {pos.tolist()} look {lookv.tolist()} flags {flags}", flush=True)
             if not np.array_equal(got.reshape(-1), want):
                 bad += 1
                 diff = np.flatnonzero((got.reshape(-1, 4) != want.reshape(-1, 4)).any(axis=1))
