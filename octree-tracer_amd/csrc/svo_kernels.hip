@@ -797,7 +797,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                 // known to be saturated (ST_SAT; a restart at level r keeps that knowledge for levels < r) and only
                 // looks at the levels below.  Final counters = min(15, old + visits), like the RESTART kernel.
                 uint32_t sat = (st >> ST_SAT_SHIFT) & 31u;
-                for (uint32_t l = sat + 1u; l <= L; l++) {  // (per lane; typically the last two or three levels)
+                for (uint32_t l = sat + 1u; l < L; l++) {  // (per lane; after the first rounds of a frame: none or one)
                     const uint32_t kk = l - 1u, shc = (uint32_t)D - kk;
                     uint32_t g = 0u;
                     if (l >= (uint32_t)SBASE) {
@@ -808,10 +808,13 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                     }
                     const uint32_t bit = (uint32_t)D - l;
                     const uint32_t p = g + ((((uint32_t)ix >> bit) & 1u) << 2 | (((uint32_t)iy >> bit) & 1u) << 1 | (((uint32_t)iz >> bit) & 1u));
-                    const uint32_t word = l == L ? leaf_w : load_word(rs, p);
+                    const uint32_t word = load_word(rs, p);
                     if ((word & 15u) == 15u && l == sat + 1u) sat = l;
                     count_visit(a.count_nodes, a.n_words, p, word);
                 }
+                // the leaf itself: word and address are at hand (a restart leaves sat below the new leaf's level)
+                if ((leaf_w & 15u) == 15u && L == sat + 1u) sat = L;
+                count_visit(a.count_nodes, a.n_words, leaf_off >> 2, leaf_w);
                 st = (st & ~(31u << ST_SAT_SHIFT)) | (sat << ST_SAT_SHIFT);
             }
             const bool too_deep = leaf_w < (kVoxelOffset << 4);  // descent stopped on an interior word
