@@ -1329,6 +1329,12 @@ static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipS
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kStackBlock, lds_bytes);
         if (e != hipSuccess) return e;
         blocks_per_cu = n > 0 ? n : 1;
+        // The occupancy query does not round LDS up to the allocation granule; measured on MI355X, 336 bytes on top of
+        // 26 KiB per workgroup already cost the sixth workgroup per CU.  Workgroups that are not resident at launch
+        // start when the first ones end and bring their reserved (longest) strips with them, so overestimating is
+        // far worse than underestimating: assume 1 KiB granules of the 160 KiB.
+        const int by_lds = (int)((160u * 1024u) / ((lds_bytes + 1023u) & ~(size_t)1023u));
+        if (by_lds >= 1 && by_lds < blocks_per_cu) blocks_per_cu = by_lds;
     }
     uint32_t blocks = (uint32_t)li.num_cus * (uint32_t)blocks_per_cu;
     if (li.grid_blocks > 0) blocks = (uint32_t)li.grid_blocks;
