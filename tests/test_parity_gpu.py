@@ -775,3 +775,28 @@ def test_tiny_origin_components(pkg, gpu, O, monu9_words, variant):
     for pos, look in (((0.0, 0.0, -0.2), (0.3, 0.1, 1.0)), ((0.0, 0.25, 0.0), (1.0, -0.2, 0.4))):
         u = O.make_uniforms(pos=pos, look=look, width=320, height=180, flags=O.F_PAUSE_ADAPTIVE)
         assert_hits_equal(_render(pkg, gpu, words, u, variant), O.trace_frame(words, u, threads=8), f"camera on a centre plane {pos}")
+
+
+def test_launch_options_do_not_change_results(pkg, gpu, O, monu9_words):
+    """Every tuning knob of svo_set_option (refill threshold, strip size, static / dynamic claiming, grid size, schedule
+    period, block shape) only changes HOW the rays are traced: the records stay bit-identical to the oracle's."""
+    terrain = pkg.scenes.terrain(seed=2, max_depth=12, cam=(0.1, 0.3, -0.2), lod_c=300.0, max_words=3_000_000)
+    G = pkg.gpu
+    defaults = {G.OPT_REFILL_MIN: 16, G.OPT_STRIP_ITEMS: 64, G.OPT_DYNAMIC_STRIPS: 1, G.OPT_GRID_BLOCKS: 0, G.OPT_SCHEDULE: 2,
+                G.OPT_BLOCK_SHAPE: 3}
+    combos = [{G.OPT_REFILL_MIN: 1}, {G.OPT_REFILL_MIN: 64}, {G.OPT_STRIP_ITEMS: 256, G.OPT_SCHEDULE: 0},
+              {G.OPT_DYNAMIC_STRIPS: 0, G.OPT_SCHEDULE: 0}, {G.OPT_GRID_BLOCKS: 7}, {G.OPT_GRID_BLOCKS: 4000},
+              {G.OPT_SCHEDULE: 1}, {G.OPT_SCHEDULE: 0}, {G.OPT_BLOCK_SHAPE: 4}, {G.OPT_BLOCK_SHAPE: 6, G.OPT_REFILL_MIN: 5},
+              {G.OPT_GRID_BLOCKS: 1, G.OPT_REFILL_MIN: 33}]
+    gpu.set_option(G.OPT_VARIANT, 1)
+    try:
+        for words, pose in ((monu9_words, ((0.1, 0.2, -1.5), (0.0, 0.0, 1.5))), (terrain, ((0.1, 0.3, -0.2), (0.4, -0.3, 1.0)))):
+            u = O.make_uniforms(pos=pose[0], look=pose[1], width=333, height=187, flags=O.F_PAUSE_ADAPTIVE)
+            want = O.trace_frame(words, u, threads=8)
+            for combo in combos:
+                for k, v in {**defaults, **combo}.items():
+                    gpu.set_option(k, v)
+                assert_hits_equal(_render(pkg, gpu, words, u, 1), want, f"options {combo}")
+    finally:
+        for k, v in defaults.items():
+            gpu.set_option(k, v)
