@@ -68,7 +68,7 @@ class FramePipeline:
     device context), so the serial tail of one frame's rays overlaps the next frames.  A rank's share of a
     sharded frame is small, and a ray is a serial chain of up to 101 dependent rounds: with one frame at a
     time the GPU idles through every frame's tail (tools/pipeline_probe.py: 1/8 of a 1080p frame takes 0.16 ms
-    alone and 0.076 ms with three frames in flight).
+    alone and 0.072 ms with three frames in flight).
 
     step() returns the most recent COMPLETED frame on rank 0 (None until the first one is ready, and on
     other ranks; with `assemble` it lives in a buffer that is reused after as many further steps as there are
