@@ -49,15 +49,18 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: validation mode for boxes with fewer GPUs than ranks -- ranks share the visible GPUs and "
                          "the gather is staged through host memory (not a performance configuration)")
-    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
                     help="consecutive frames rotate over this many HIP streams / device contexts, so the serial tail of one "
                          "frame's rays overlaps the next frames.  0 = default: 1 at N=1 (frames serial, which is what "
-                         "roofline.* describes), 3 at N>1 (a rank's share of a sharded frame is too small to fill a GPU)")
+                         "roofline.* describes), 3 at N>1 (a rank's share of a sharded frame is too small to fill a GPU).  "
+                         "More than 3 needs more hardware queues than ROCm's default of 4: GPU_MAX_HW_QUEUES=8 is set then")
     ap.add_argument("--wire", default="packed12", choices=["packed12", "full16"],
                     help="N>1: what the frame-end gather carries per ray: the 12-byte wire record (the fourth word of svo_hit "
                          "repeats bits of the third; rank 0 rebuilds it while un-permuting) or the full 16-byte record")
     ap.add_argument("--cpu-frac", type=int, default=1, help="cpu_baseline traces the top 1/n of the frame's rows")
     a = ap.parse_args()
+    if a.frames_in_flight > 3:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: one hardware queue per lane
 
     import torch
     import torch.distributed as dist

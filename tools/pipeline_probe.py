@@ -29,7 +29,7 @@ def main():
     r0.set_flags(pause_adaptive=True, shadows=False)
     r0.update(pkg.Settings(), pkg.Character(cam, look))
     lanes = [(gpu0, r0, torch.cuda.current_stream())]
-    for _ in range(3):
+    for _ in range(max(int(x) for x in a.inflight.split(",")) - 1):
         s = torch.cuda.Stream()
         g = pkg.Gpu(0, stream=s.cuda_stream)
         r = pkg.Render.share_nodes(g, r0)
