@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--wire", default="packed12", choices=["packed12", "full16"],
                     help="N>1: what the frame-end gather carries per ray: the 12-byte wire record (the fourth word of svo_hit "
                          "repeats bits of the third; rank 0 rebuilds it while un-permuting) or the full 16-byte record")
+    ap.add_argument("--force-pipeline", action="store_true",
+                    help="validation: run the N>1 code path (lanes, wire records, RCCL gather, assemble) with a one-rank "
+                         "process group on a single GPU")
     ap.add_argument("--cpu-frac", type=int, default=1, help="cpu_baseline traces the top 1/n of the frame's rows")
     a = ap.parse_args()
     if a.frames_in_flight > 3:
@@ -76,8 +79,10 @@ def main():
     if a.backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    pipelined = world > 1 or a.force_pipeline
+    if pipelined:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -87,7 +92,7 @@ def main():
     lib_path = os.path.join(ROOT, "octree-tracer_amd", "libsvo_hip.so")
     if not os.path.exists(lib_path) and rank == 0:
         entry.build()
-    if world > 1:
+    if pipelined:
         dist.barrier()
     pkg = entry.load_package()
     wl = WORKLOADS[a.workload]
@@ -107,7 +112,7 @@ def main():
     tw, th = a.tile_w, a.tile_h
     n_rays = W * H
     if a.frames_in_flight == 0:
-        a.frames_in_flight = 1 if (world == 1 or a.backend == "gloo") else 3
+        a.frames_in_flight = 1 if (not pipelined or a.backend == "gloo") else 3
     # lane 0 = the context above on torch's current stream; further lanes: own HIP stream + context, same node buffer
     lanes = [(gpu, render, torch.cuda.current_stream())]
     for _ in range(a.frames_in_flight - 1):
@@ -116,7 +121,7 @@ def main():
         render_k = pkg.Render.share_nodes(gpu_k, render)
         gpu_k.set_option(pkg.gpu.OPT_TIMING, max(a.steps, 1))
         lanes.append((gpu_k, render_k, s_k))
-    if world == 1 and len(lanes) > 1:
+    if not pipelined and len(lanes) > 1:
         bufs = [r.alloc_hits(n_rays) for _, r, _ in lanes]
         counter = [0]
 
@@ -125,7 +130,7 @@ def main():
             counter[0] += 1
             lanes[k][1].render(hits=bufs[k])
             return bufs[k]
-    elif world == 1:
+    elif not pipelined:
         hits = render.alloc_hits(n_rays)
 
         def step():
@@ -157,13 +162,13 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if pipelined:
             dist.barrier()
             torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         step()
-    if world > 1:
+    if pipelined:
         pipe.drain()
     barrier()
     for g, _, _ in lanes:
@@ -171,7 +176,7 @@ def main():
     t_start = time.perf_counter()
     for _ in range(a.steps):
         out = step()
-    if world > 1:
+    if pipelined:
         out = pipe.drain()  # every one of the K frames is gathered and assembled inside the timed region
     barrier()
     elapsed = time.perf_counter() - t_start
@@ -179,7 +184,7 @@ def main():
     # around each launch on the launch stream
     kms = np.concatenate([g.timing_collect() for g, _, _ in lanes])
     assert len(kms) == a.steps
-    if world > 1:
+    if pipelined:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -190,7 +195,7 @@ def main():
         value = n_rays * a.steps / elapsed / 1e6
         kernel_avg_ms = float(np.mean(kms))
         # rays this rank's launch traced (rank 0 owns the most tiles)
-        rays_per_launch = n_rays if world == 1 else pkg.sharding.local_tile_count(W, H, tw, th, 0, world) * tw * th
+        rays_per_launch = n_rays if not pipelined else pkg.sharding.local_tile_count(W, H, tw, th, 0, world) * tw * th
         frame = out.reshape(-1, 4).cpu().numpy().view(np.uint32)
         result = {
             "metric": "Mrays/sec at 1920x1080, depth-16 SVO; achieved HBM GB/s vs peak",
@@ -199,7 +204,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
             "config": {"workload": a.workload, "width": W, "height": H, "octree_max_depth": wl["max_depth"],
                        "node_words": int(words.size), "node_bytes": int(words.size) * 4, "rays_per_step": n_rays,
-                       "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight, "backend": a.backend if world > 1 else None, "sharding": "none" if world == 1 else f"tiles {tw}x{th} round-robin, 1 RCCL gather per frame ({12 if a.wire == 'packed12' else 16} B/ray) overlapped with the following frames' traces",
+                       "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight, "backend": a.backend if pipelined else None, "sharding": "none" if not pipelined else f"tiles {tw}x{th} round-robin, 1 RCCL gather per frame ({12 if a.wire == 'packed12' else 16} B/ray) overlapped with the following frames' traces",
                        "scene_gen_s": round(gen_s, 1)},
         }
         cpu = None
@@ -246,7 +251,7 @@ def main():
         if cpu is not None:
             result["cpu_baseline"] = cpu
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if pipelined:
         dist.barrier()
         dist.destroy_process_group()
 

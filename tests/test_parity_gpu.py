@@ -800,3 +800,24 @@ def test_launch_options_do_not_change_results(pkg, gpu, O, monu9_words):
     finally:
         for k, v in defaults.items():
             gpu.set_option(k, v)
+
+
+def test_bench_multi_gpu_path_with_one_rank(pkg, gpu):
+    """bench.py's N > 1 code path end to end (three lanes, 12-byte wire records, asynchronous RCCL gather, assemble on
+    rank 0, timing collection, oracle check of the assembled frame) with a one-rank process group on this GPU."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-pipeline", "--steps", "24", "--warmup", "3"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] is True
+    assert line["config"]["frames_in_flight"] == 3 and "12 B/ray" in line["config"]["sharding"]
+    assert line["steps"] == 24 and line["value"] > 100
