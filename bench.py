@@ -82,7 +82,11 @@ def main():
     pipelined = world > 1 or a.force_pipeline
     if pipelined:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
+        if "MASTER_PORT" not in os.environ:  # only the single-process validation mode gets here without a launcher
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
