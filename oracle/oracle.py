@@ -32,7 +32,10 @@ class Uniforms(C.Structure):
 
 
 def build(force=False):
-    """Compile the oracle with gcc (strict IEEE flags live in oracle/Makefile)."""
+    """Compile the oracle with gcc (strict IEEE flags live in oracle/Makefile).  SVO_ORACLE_LIB names a prebuilt
+    library instead (the sanitizer build of tools/sanitize_cpu.sh)."""
+    if os.environ.get("SVO_ORACLE_LIB"):
+        return os.environ["SVO_ORACLE_LIB"]
     src = os.path.join(_HERE, "svo_oracle.c")
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src),
@@ -49,8 +52,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    build()
-    L = C.CDLL(_LIB_PATH)
+    L = C.CDLL(build())
     vp, u8p, u32p, fp = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_float)
     L.oracle_tree_new.restype = vp
     L.oracle_tree_new.argtypes = [C.c_uint8]
