@@ -183,24 +183,36 @@ __device__ __forceinline__ void count_add(uint32_t *nodes, uint32_t p, uint32_t 
 
 // Called by all lanes that are at the same level of their descent.  Rays of a wave are coherent: near the root all 64
 // lanes visit the same word, and 64 lanes racing their compare-and-swaps on one word cost 64 atomics per increment
-// (a 1080p frame took 400 ms that way).  Lanes with the same word are therefore grouped (ballot on the address of the
-// first lane still waiting) and one of them adds the size of the group; once groups are down to single lanes the
-// rest go individually (distinct addresses, no contention).
+// (a 1080p frame took 400 ms that way).  Lanes with the same word are therefore grouped and the first lane of a group
+// adds the size of the group; all groups issue their compare-and-swap together, after the grouping.  Neighbouring lanes
+// trace neighbouring pixels, so equal addresses mostly sit in runs of adjacent lanes: with few runs the groups are
+// exact (one ballot per distinct address merges runs that share a word), with many runs every run is its own group
+// (no loop; two runs on one word then cost two atomics, which is still correct).
 __device__ __forceinline__ void count_visit(uint32_t *nodes, uint32_t n_words, uint32_t p, uint32_t word) {
-    bool need = p < n_words && (word & 15u) < 15u;
-    uint64_t todo = __ballot(need);
+    const bool need = p < n_words && (word & 15u) < 15u;
+    const uint64_t needmask = __ballot(need);
+    if (!needmask) return;
     const uint32_t lane = __lane_id();
-    while (todo) {
-        const uint32_t leader = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
-        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)leader);
-        const uint64_t grp = __ballot(need && p == p0);
-        const uint32_t n = (uint32_t)__popcll(grp);
-        if (n == 1u) break;
-        if (lane == leader) count_add(nodes, p, word, n);
-        if (p == p0) need = false;
-        todo &= ~grp;
+    const uint32_t prev = (uint32_t)__shfl_up((int)p, 1);  // only looked at when lane - 1 is in needmask
+    const bool head = need && (lane == 0u || !((needmask >> (lane - 1u)) & 1ull) || prev != p);
+    const uint64_t headmask = __ballot(head);
+    uint32_t n = 0u;  // visits this lane reports: the size of its group on the group's first lane, 0 elsewhere
+    if (__popcll(headmask) <= 8) {
+        uint64_t todo = headmask;
+        while (todo) {
+            const uint32_t leader = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+            const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)leader);
+            const uint64_t grp = __ballot(need && p == p0);
+            if (lane == leader) n = (uint32_t)__popcll(grp);
+            todo &= ~grp;
+        }
+    } else {
+        const uint64_t above = lane == 63u ? 0ull : (~0ull << (lane + 1u));
+        const uint64_t stop = (headmask | ~needmask) & above;  // where this lane's run ends
+        const uint32_t end = stop ? (uint32_t)__ffsll((unsigned long long)stop) - 1u : 64u;
+        if (head) n = end - lane;
     }
-    if (need) count_add(nodes, p, word, 1u);
+    if (n) count_add(nodes, p, word, n);
 }
 
 __device__ __forceinline__ void trace_one_restart(const TraceArgs &a, rsrc_t rs, bool misc_bool, bool counter_hits,
