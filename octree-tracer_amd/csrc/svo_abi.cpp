@@ -426,8 +426,7 @@ int svo_ctx_destroy(svo_ctx *ctx) {
     }
     for (void *p : {ctx->shade_hits, ctx->shade_aux, ctx->shade_rays, ctx->shade_shadow, ctx->scatter_buf})
         if (p) (void)hipFree(p);
-    if (ctx->scan_sub) (void)hipFree(ctx->scan_sub);
-    if (ctx->scan_unsub) (void)hipFree(ctx->scan_unsub);
+    if (ctx->scan_sub) (void)hipFree(ctx->scan_sub);  // scan_unsub is the second half of the same allocation
     if (ctx->stage) (void)hipFree(ctx->stage);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -779,11 +778,14 @@ int svo_scan_dispatch(svo_ctx *ctx, uint32_t node_length) {
     if (rc) return rc;
     if (!ctx->scan_sub) {
         // Compute::new: two lists of 1 024 000 words, zero-initialised (compute.rs:46-64)
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->scan_sub, kScanCapacity * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->scan_unsub, kScanCapacity * sizeof(uint32_t)));
+        // (one allocation for both, so that a failure cannot leave half of the pair behind)
+        uint32_t *lists = nullptr;
+        HIP_TRY(ctx, hipMalloc((void **)&lists, 2 * kScanCapacity * sizeof(uint32_t)));
+        ctx->scan_sub = lists;
+        ctx->scan_unsub = lists + kScanCapacity;
+        ctx->scan_capacity = kScanCapacity;
         HIP_TRY(ctx, hipMemsetAsync(ctx->scan_sub, 0, sizeof(uint32_t), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->scan_unsub, 0, sizeof(uint32_t), ctx->stream));
-        ctx->scan_capacity = kScanCapacity;
     }
     uint32_t n = node_length < ctx->capacity ? node_length : (uint32_t)ctx->capacity;
     HIP_TRY(ctx, svo::launch_scan(ctx->nodes, n, node_length, ctx->scan_sub, ctx->scan_unsub,
