@@ -62,8 +62,8 @@ struct svo_ctx {
     uint32_t sched_period = 2;  // frames between schedule rebuilds (tools/perf_probe.py --motion: 2 keeps the gain under camera motion)
     int frame_parity = 0;
     // shading pass scratch (svo_render with rgba_out)
-    void *shade_hits = nullptr, *shade_aux = nullptr, *shade_rays = nullptr, *shade_shadow = nullptr;
-    size_t shade_hits_bytes = 0, shade_aux_bytes = 0, shade_rays_bytes = 0, shade_shadow_bytes = 0;
+    void *shade_hits = nullptr, *shade_aux = nullptr, *shade_rays = nullptr, *shade_shadow = nullptr, *shade_skip = nullptr;
+    size_t shade_hits_bytes = 0, shade_aux_bytes = 0, shade_rays_bytes = 0, shade_shadow_bytes = 0, shade_skip_bytes = 0;
     uint32_t *debug_buf = nullptr;  // caller-provided device buffer for the per-wave timeline (diagnostics)
     uint32_t strip_items = 64;
     bool dynamic_strips = true;
@@ -109,6 +109,7 @@ struct TraceOpts {
     float *aux_t = nullptr;    // t_current per record (shading pass)
     bool count_rays = false;   // explicit rays also bump hit counters (the shadow ray passes primary = true, shader.wgsl:276)
     int sched_slot = 0;        // which schedule history this launch feeds (0: primary frame, 1: shadow rays)
+    const uint8_t *skip = nullptr;  // explicit rays: slots without a ray (secondary rays of pixels that hit nothing)
 };
 
 int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo_hit *hits, const TraceOpts &opt) {
@@ -135,6 +136,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     a.status = ctx->status;
     a.refill_min = ctx->refill_min;
     a.debug = ctx->debug_buf;
+    a.skip = opt.skip;
     // shader.wgsl:159: counters are live unless pause_adaptive; rays handed in by the caller (svo_trace_rays) never count
     const bool counting = (work.mode != 2 || opt.count_rays) && !(ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE);
     a.count_nodes = counting ? ctx->nodes : nullptr;
@@ -263,7 +265,10 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         if (rc) return rc;
         rc = ensure_dev(ctx, &ctx->shade_shadow, &ctx->shade_shadow_bytes, n * sizeof(svo_hit));
         if (rc) return rc;
-        HIP_TRY(ctx, svo::launch_secondary_gen(a, (const float *)ctx->shade_aux, (float *)ctx->shade_rays, 1u, (uint32_t)n, ctx->stream));
+        rc = ensure_dev(ctx, &ctx->shade_skip, &ctx->shade_skip_bytes, n);
+        if (rc) return rc;
+        HIP_TRY(ctx, svo::launch_secondary_gen(a, (const float *)ctx->shade_aux, (float *)ctx->shade_rays, (uint8_t *)ctx->shade_skip,
+                                               (svo_hit *)ctx->shade_shadow, 1u, (uint32_t)n, ctx->stream));
         svo::WorkDesc rw{};
         rw.mode = 2;
         rw.n_items = (uint32_t)n;
@@ -271,6 +276,7 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         TraceOpts shadow;
         shadow.count_rays = true;
         shadow.sched_slot = 1;
+        shadow.skip = (const uint8_t *)ctx->shade_skip;
         rc = trace_launch(ctx, rw, (const float *)ctx->shade_rays, (svo_hit *)ctx->shade_shadow, shadow);
         if (rc) return rc;
     }
@@ -307,8 +313,10 @@ int trace_secondary(svo_ctx *ctx, const svo::WorkDesc &work, uint32_t n_secondar
     a.u = ctx->uniforms;
     a.work = work;
     a.hits = primary;
-    HIP_TRY(ctx, svo::launch_secondary_gen(a, (const float *)ctx->shade_aux, (float *)ctx->shade_rays, n_secondary, (uint32_t)n,
-                                           ctx->stream));
+    rc = ensure_dev(ctx, &ctx->shade_skip, &ctx->shade_skip_bytes, n * n_secondary);
+    if (rc) return rc;
+    HIP_TRY(ctx, svo::launch_secondary_gen(a, (const float *)ctx->shade_aux, (float *)ctx->shade_rays, (uint8_t *)ctx->shade_skip, secondary,
+                                           n_secondary, (uint32_t)n, ctx->stream));
     svo::WorkDesc rw{};
     rw.mode = 2;
     rw.n_items = (uint32_t)(n * n_secondary);
@@ -316,6 +324,7 @@ int trace_secondary(svo_ctx *ctx, const svo::WorkDesc &work, uint32_t n_secondar
     TraceOpts sopt;
     sopt.count_rays = true;  // like the shadow ray, which passes primary = true (shader.wgsl:276)
     sopt.sched_slot = 1;
+    sopt.skip = (const uint8_t *)ctx->shade_skip;
     return trace_launch(ctx, rw, (const float *)ctx->shade_rays, secondary, sopt);
 }
 
@@ -424,7 +433,7 @@ int svo_ctx_destroy(svo_ctx *ctx) {
         if (sc.cost) (void)hipFree(sc.cost);
         if (sc.order) (void)hipFree(sc.order);
     }
-    for (void *p : {ctx->shade_hits, ctx->shade_aux, ctx->shade_rays, ctx->shade_shadow, ctx->scatter_buf})
+    for (void *p : {ctx->shade_hits, ctx->shade_aux, ctx->shade_rays, ctx->shade_shadow, ctx->shade_skip, ctx->scatter_buf})
         if (p) (void)hipFree(p);
     if (ctx->scan_sub) (void)hipFree(ctx->scan_sub);  // scan_unsub is the second half of the same allocation
     if (ctx->stage) (void)hipFree(ctx->stage);

@@ -52,6 +52,7 @@ struct TraceArgs {
     const uint32_t *order;      // STACK, optional: schedule built by strip_order_kernel (8 lengths + 8 lists)
     uint32_t order_cap;         // entries reserved per list
     uint32_t *debug;            // optional: 8 words per wave (start, queue-dry, end ticks of 10 ns, rounds, active-lane sum, ...)
+    const uint8_t *skip;        // mode 2, optional: one byte per ray; non-zero = no ray here, its (all-zero) record is already written
 };
 
 struct LaunchInfo {
@@ -76,8 +77,9 @@ constexpr uint32_t kOrderHistWords = 64 * 16;      // chunk histograms of the sc
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
                        uint32_t cap, bool build_schedule, hipStream_t stream);
 
-hipError_t launch_secondary_gen(const TraceArgs &args, const float *aux_t, float *rays, uint32_t n_secondary, uint32_t n_records,
-                                hipStream_t stream);
+// secondary rays of the hit pixels of args.hits; pixels without a hit get skip = 1 and a zero record in `out` instead of a ray
+hipError_t launch_secondary_gen(const TraceArgs &args, const float *aux_t, float *rays, uint8_t *skip, svo_hit *out,
+                                uint32_t n_secondary, uint32_t n_records, hipStream_t stream);
 hipError_t launch_shade(const TraceArgs &args, const svo_hit *shadow_hits, uint32_t *rgba, hipStream_t stream);
 hipError_t launch_diag_gather(const uint32_t *buf, uint32_t n_words, uint32_t stride_words, uint32_t n_loads, uint32_t *sink,
                               hipStream_t stream);

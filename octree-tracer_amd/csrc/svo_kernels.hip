@@ -220,6 +220,7 @@ __device__ __forceinline__ void trace_one_restart(const TraceArgs &a, rsrc_t rs,
     const bool count = a.count_nodes != nullptr;
     Item it = decode_item(a.work, q);
     if (!it.valid) return;
+    if (a.work.mode == 2 && a.skip && a.skip[q]) return;  // no ray: the producer wrote the record
     RayIn r = item_ray(a, it);
     float pos[3], dir[3], dist;
     if (!ray_enter(r, pos, dir, dist)) {
@@ -653,6 +654,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                     uint32_t gout = 0;
                     if (q < strip_end) {
                         ItemFast it = decode_item_fast(a.work, q);
+                        if (a.work.mode == 2 && a.skip && a.skip[q]) it.valid = false;  // no ray: the producer wrote the record
                         if (it.valid) {
                             RayIn r;
                             if (a.work.mode == 2) {
@@ -1185,8 +1187,8 @@ __device__ __forceinline__ uint32_t mix32(uint32_t a) {
     return a;
 }
 
-__global__ __launch_bounds__(256) void secondary_gen_kernel(TraceArgs a, const float *aux_t, float *rays, uint32_t n_secondary,
-                                                            uint32_t n_records) {
+__global__ __launch_bounds__(256) void secondary_gen_kernel(TraceArgs a, const float *aux_t, float *rays, uint8_t *skip, svo_hit *out,
+                                                            uint32_t n_secondary, uint32_t n_records) {
     const float sl = sqrtf((a.u.sun_dir[0] * a.u.sun_dir[0] + a.u.sun_dir[1] * a.u.sun_dir[1]) + a.u.sun_dir[2] * a.u.sun_dir[2]);
     const float s0 = a.u.sun_dir[0] / sl, s1 = a.u.sun_dir[1] / sl, s2 = a.u.sun_dir[2] / sl;  // normalize(u.sun_dir.xyz)
     const uint32_t width = (uint32_t)a.u.dimensions[0];
@@ -1195,38 +1197,44 @@ __global__ __launch_bounds__(256) void secondary_gen_kernel(TraceArgs a, const f
         if (!it.valid) continue;
         const uint4 rec = reinterpret_cast<const uint4 *>(a.hits)[it.out];
         const bool hit = (rec.z >> 16) & 1u;
-        float org[3] = {5.0f, 5.0f, 5.0f};  // no hit: a ray that never enters the cube
-        float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
-        if (hit) {
-            RayIn r = gen_ray(a.u, it.px, it.py);
-            float pos[3], dir[3], dist;
-            ray_enter(r, pos, dir, dist);
-            n0 = code_to_normal(rec.w & 3u); n1 = code_to_normal((rec.w >> 2) & 3u); n2 = code_to_normal((rec.w >> 4) & 3u);
-            float h0 = pos[0], h1 = pos[1], h2 = pos[2];  // HitInfo.pos = voxel_pos of the last find_voxel
-            if ((rec.z & 0xFFu) != 0u) {
-                const float t = aux_t[it.out];
-                h0 = pos[0] + dir[0] * t - n0 * 0.000002f;
-                h1 = pos[1] + dir[1] * t - n1 * 0.000002f;
-                h2 = pos[2] + dir[2] * t - n2 * 0.000002f;
+        if (!hit) {
+            // No secondary rays from this pixel.  fs_main traces none; the record set still has a slot for them, which holds
+            // what the trace kernels write for a ray that never enters the cube: all zeros.  The trace skips these slots.
+            for (uint32_t k = 0; k < n_secondary; k++) {
+                const uint64_t slot = (uint64_t)k * n_records + it.out;
+                skip[slot] = 1u;
+                reinterpret_cast<uint4 *>(out)[slot] = make_uint4(0u, 0u, 0u, 0u);
             }
-            org[0] = h0 + n0 * 0.0000025f; org[1] = h1 + n1 * 0.0000025f; org[2] = h2 + n2 * 0.0000025f;  // :276
+            continue;
         }
+        RayIn r = gen_ray(a.u, it.px, it.py);
+        float pos[3], dir[3], dist;
+        ray_enter(r, pos, dir, dist);
+        const float n0 = code_to_normal(rec.w & 3u), n1 = code_to_normal((rec.w >> 2) & 3u), n2 = code_to_normal((rec.w >> 4) & 3u);
+        float h0 = pos[0], h1 = pos[1], h2 = pos[2];  // HitInfo.pos = voxel_pos of the last find_voxel
+        if ((rec.z & 0xFFu) != 0u) {
+            const float t = aux_t[it.out];
+            h0 = pos[0] + dir[0] * t - n0 * 0.000002f;
+            h1 = pos[1] + dir[1] * t - n1 * 0.000002f;
+            h2 = pos[2] + dir[2] * t - n2 * 0.000002f;
+        }
+        const float org[3] = {h0 + n0 * 0.0000025f, h1 + n1 * 0.0000025f, h2 + n2 * 0.0000025f};  // :276
         for (uint32_t k = 0; k < n_secondary; k++) {
-            float d0 = 1.0f, d1 = 1.0f, d2 = 1.0f;
-            if (hit) {
-                if (k == 0u) {
-                    d0 = -s0; d1 = -s1; d2 = -s2;  // the shadow ray, shader.wgsl:276
-                } else {
-                    const uint32_t hsh = mix32((it.py * width + it.px) * 4u + k + 0x9E3779B9u);
-                    float e0 = (float)(int)(hsh & 1023u) - 511.5f, e1 = (float)(int)((hsh >> 10) & 1023u) - 511.5f,
-                          e2 = (float)(int)((hsh >> 20) & 1023u) - 511.5f;
-                    const float len = sqrtf((e0 * e0 + e1 * e1) + e2 * e2);
-                    e0 = e0 / len; e1 = e1 / len; e2 = e2 / len;
-                    const bool flip = (n0 * e0 + n1 * e1) + n2 * e2 < 0.0f;
-                    d0 = flip ? -e0 : e0; d1 = flip ? -e1 : e1; d2 = flip ? -e2 : e2;
-                }
+            float d0, d1, d2;
+            if (k == 0u) {
+                d0 = -s0; d1 = -s1; d2 = -s2;  // the shadow ray, shader.wgsl:276
+            } else {
+                const uint32_t hsh = mix32((it.py * width + it.px) * 4u + k + 0x9E3779B9u);
+                float e0 = (float)(int)(hsh & 1023u) - 511.5f, e1 = (float)(int)((hsh >> 10) & 1023u) - 511.5f,
+                      e2 = (float)(int)((hsh >> 20) & 1023u) - 511.5f;
+                const float len = sqrtf((e0 * e0 + e1 * e1) + e2 * e2);
+                e0 = e0 / len; e1 = e1 / len; e2 = e2 / len;
+                const bool flip = (n0 * e0 + n1 * e1) + n2 * e2 < 0.0f;
+                d0 = flip ? -e0 : e0; d1 = flip ? -e1 : e1; d2 = flip ? -e2 : e2;
             }
-            float *dst = rays + 6ull * ((uint64_t)k * n_records + it.out);
+            const uint64_t slot = (uint64_t)k * n_records + it.out;
+            skip[slot] = 0u;
+            float *dst = rays + 6ull * slot;
             dst[0] = org[0]; dst[1] = org[1]; dst[2] = org[2];
             dst[3] = d0; dst[4] = d1; dst[5] = d2;
         }
@@ -1270,12 +1278,12 @@ __global__ __launch_bounds__(256) void shade_kernel(TraceArgs a, const svo_hit *
     }
 }
 
-hipError_t launch_secondary_gen(const TraceArgs &args, const float *aux_t, float *rays, uint32_t n_secondary, uint32_t n_records,
-                                hipStream_t stream) {
+hipError_t launch_secondary_gen(const TraceArgs &args, const float *aux_t, float *rays, uint8_t *skip, svo_hit *out,
+                                uint32_t n_secondary, uint32_t n_records, hipStream_t stream) {
     (void)hipGetLastError();
     uint32_t blocks = (args.work.n_items + 255u) / 256u;
     if (blocks > 4096u) blocks = 4096u;
-    hipLaunchKernelGGL(secondary_gen_kernel, dim3(blocks), dim3(256), 0, stream, args, aux_t, rays, n_secondary, n_records);
+    hipLaunchKernelGGL(secondary_gen_kernel, dim3(blocks), dim3(256), 0, stream, args, aux_t, rays, skip, out, n_secondary, n_records);
     return hipGetLastError();
 }
 
