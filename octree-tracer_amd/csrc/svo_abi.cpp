@@ -48,6 +48,7 @@ struct svo_ctx {
     // scheduling feedback (strip order from an earlier frame of the same work layout); slot 1: shadow rays
     struct Sched {
         uint8_t *cost = nullptr;
+        uint8_t *cls_now = nullptr;  // launches with a skip mask: this frame's classes (0xFF = strip without a ray)
         uint32_t *order = nullptr;
         size_t cap = 0;
         bool valid = false;
@@ -145,21 +146,32 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     const uint32_t n_strips = (wd.n_items + 63u) / 64u;
     const bool schedule = ctx->schedule && n_strips <= svo::kMaxScheduledStrips;
     svo_ctx::Sched &sc = ctx->sched[opt.sched_slot & 1];
+    const bool filtered = stack && schedule && opt.skip != nullptr;
     if (stack && schedule) {
         if (sc.cap < n_strips) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (sc.cost) (void)hipFree(sc.cost);
+            if (sc.cls_now) (void)hipFree(sc.cls_now);
             if (sc.order) (void)hipFree(sc.order);
             sc = svo_ctx::Sched{};
             size_t want = n_strips < 4096 ? 4096 : n_strips;
             HIP_TRY(ctx, hipMalloc((void **)&sc.cost, want + 32 + svo::kOrderHistWords * sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMalloc((void **)&sc.cls_now, want + 32 + svo::kOrderHistWords * sizeof(uint32_t)));
             HIP_TRY(ctx, hipMalloc((void **)&sc.order, (want + 8 * 24 + 8) * sizeof(uint32_t)));
             sc.cap = want;
         }
-        // the order is only meaningful for the same work layout (same pixels behind every strip)
+        // costs and order are only meaningful for the same work layout (same pixels behind every strip)
         if (sc.valid && memcmp(&sc.key, &wd, sizeof(wd)) != 0) sc.valid = false;
-        a.order = sc.valid ? sc.order : nullptr;
         a.order_cap = (n_strips + 7u) / 8u + 16u;  // a list holds ceil(n_class / 8) strips of each of the 16 classes
+        if (filtered) {
+            // slots without a ray (secondary rays of pixels that hit nothing): this frame's lists leave out the strips
+            // that consist of nothing else, ordered by the costs of an earlier frame when there are any
+            HIP_TRY(ctx, svo::launch_schedule_skipping(opt.skip, wd.n_items, sc.valid ? sc.cost : nullptr, sc.cls_now, sc.order, n_strips,
+                                                       a.order_cap, ctx->stream));
+            a.order = sc.order;
+        } else {
+            a.order = sc.valid ? sc.order : nullptr;
+        }
     }
     svo::LaunchInfo li{};
     li.variant = stack ? SVO_VARIANT_STACK : SVO_VARIANT_RESTART;
@@ -203,9 +215,10 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         // frames is a backstop for node buffers written behind this context's back).
         const bool same_input = (wd.mode != 2 || opt.sched_slot == 1) && sc.built_nodes_version == ctx->nodes_version &&
                                 memcmp(&sc.built_uniforms, &ctx->uniforms, sizeof(svo_uniforms)) == 0 && sc.age < 64;
-        const bool rebuild = schedule && (a.order == nullptr || (!same_input && sc.age + 1 >= ctx->sched_period));
+        const bool rebuild = schedule && (!sc.valid || (!same_input && sc.age + 1 >= ctx->sched_period));
+        // (a launch with a skip mask builds its lists before the trace, every frame: here only the costs are measured)
         HIP_TRY(ctx, svo::launch_post(a, li, rebuild ? sc.cost : nullptr, sc.order, n_strips, (n_strips + 7u) / 8u + 16u,
-                                      rebuild, ctx->stream));
+                                      rebuild && !filtered, ctx->stream));
         ctx->frame_parity ^= 1;
         if (rebuild) {
             sc.key = wd;
@@ -431,6 +444,7 @@ int svo_ctx_destroy(svo_ctx *ctx) {
     if (ctx->defer_buf) (void)hipFree(ctx->defer_buf);
     for (auto &sc : ctx->sched) {
         if (sc.cost) (void)hipFree(sc.cost);
+        if (sc.cls_now) (void)hipFree(sc.cls_now);
         if (sc.order) (void)hipFree(sc.order);
     }
     for (void *p : {ctx->shade_hits, ctx->shade_aux, ctx->shade_rays, ctx->shade_shadow, ctx->shade_skip, ctx->scatter_buf})

@@ -77,6 +77,9 @@ constexpr uint32_t kOrderHistWords = 64 * 16;      // chunk histograms of the sc
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
                        uint32_t cap, bool build_schedule, hipStream_t stream);
 
+// explicit rays with a skip mask: this frame's strip lists without the strips that hold no ray (classes from `prev`, or screen order)
+hipError_t launch_schedule_skipping(const uint8_t *skip, uint32_t n_items, const uint8_t *prev, uint8_t *cls, uint32_t *sched,
+                                    uint32_t n_strips, uint32_t cap, hipStream_t stream);
 // secondary rays of the hit pixels of args.hits; pixels without a hit get skip = 1 and a zero record in `out` instead of a ray
 hipError_t launch_secondary_gen(const TraceArgs &args, const float *aux_t, float *rays, uint8_t *skip, svo_hit *out,
                                 uint32_t n_secondary, uint32_t n_records, hipStream_t stream);

@@ -1387,6 +1387,39 @@ hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t
     return ge ? launch_stack<true, kStackLevels>(args, li, stream) : launch_stack<false, kStackLevels>(args, li, stream);
 }
 
+// Explicit rays with a skip mask (secondary rays: most slots of a frame can be empty): cost classes for THIS frame's
+// schedule -- 0xFF, which strip_order_kernel leaves out of the lists, for strips without a single ray, else the class the
+// strip had when costs were last measured (0 when there is no measurement: screen order) -- and the lists built from
+// them.  Strips that are not in a list are never claimed, so empty slots cost the trace nothing.
+__global__ __launch_bounds__(256) void strip_classes_kernel(const uint8_t *skip, uint32_t n_items, const uint8_t *prev, uint8_t *cls,
+                                                            uint32_t n_strips) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= n_strips) return;
+    bool empty = true;
+    if ((uint64_t)s * 64u + 64u <= n_items) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(skip + (uint64_t)s * 64u);  // the mask is 256-byte aligned (hipMalloc)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint4 v = p[i];  // the producer writes 0 or 1
+            empty = empty && v.x == 0x01010101u && v.y == 0x01010101u && v.z == 0x01010101u && v.w == 0x01010101u;
+        }
+    } else {
+        for (uint32_t q = s * 64u; q < n_items; q++) empty = empty && skip[q] != 0u;
+    }
+    cls[s] = empty ? (uint8_t)0xFFu : (prev ? prev[s] : (uint8_t)0u);
+}
+
+hipError_t launch_schedule_skipping(const uint8_t *skip, uint32_t n_items, const uint8_t *prev, uint8_t *cls, uint32_t *sched,
+                                    uint32_t n_strips, uint32_t cap, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(strip_classes_kernel, dim3((n_strips + 255u) / 256u), dim3(256), 0, stream, skip, n_items, prev, cls, n_strips);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(cls + ((n_strips + 15u) & ~15u));  // same layout as the cost buffer
+    hipLaunchKernelGGL(strip_hist_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, (const uint8_t *)cls, n_strips, hist);
+    hipLaunchKernelGGL(strip_order_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, (const uint8_t *)cls,
+                       (const uint32_t *)hist, sched, n_strips, cap);
+    return hipGetLastError();
+}
+
 // After the STACK kernel: deferred rays, per-strip cost classes (cost != nullptr), counter re-arm; and, when
 // `build_schedule`, the strip lists for the next frames.
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
