@@ -100,6 +100,10 @@ typedef enum svo_option {
     SVO_OPT_DEBUG_BUFFER = 7, /* device pointer receiving 8 words per wave: start, queue-dry, end (10 ns ticks), rounds, ... */
     SVO_OPT_SCAN_CLEARS_COUNTERS = 11, /* 1: svo_scan_dispatch also zeroes the hit counters it has scanned, so that the
                                           host need not re-upload the whole array to reset them (svo_nodes_scatter) */
+    SVO_OPT_FUSED_SHADOWS = 12, /* shaded frames with shadows (svo_render* with rgba_out), STACK variant: 1 = the lane that finds a hit goes
+                                   on with that pixel's shadow ray inside the primary launch; 0 = shadow rays are a second launch;
+                                   2 (default) = fused for trees deeper than 16 levels (SVO_OPT_TREE_DEPTH) and frames of 4 Mpixel
+                                   and more, where it measured faster.  The image is the same either way. */
     SVO_OPT_PRIO_STEPS = 6   /* accepted and ignored: raising the issue priority of waves with old rays measured no effect and
                                 left the kernel */
 } svo_option;

@@ -3,6 +3,7 @@
 // and the device halves of render.rs / compute.rs (citations in the header).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -40,6 +41,7 @@ struct svo_ctx {
     int grid_blocks = 0;
     uint32_t refill_min = 16;
     bool scan_clears = false;
+    int fused_shadows = 2;  // 0: off, 1: on, 2: by frame size and tree depth (see trace_common)
     void *scatter_buf = nullptr;
     size_t scatter_bytes = 0;
     uint32_t prio_steps = 0;
@@ -111,6 +113,7 @@ struct TraceOpts {
     bool count_rays = false;   // explicit rays also bump hit counters (the shadow ray passes primary = true, shader.wgsl:276)
     int sched_slot = 0;        // which schedule history this launch feeds (0: primary frame, 1: shadow rays)
     const uint8_t *skip = nullptr;  // explicit rays: slots without a ray (secondary rays of pixels that hit nothing)
+    svo_hit *shadow_out = nullptr;  // STACK: trace the shadow ray of every hit inside this launch, records here
 };
 
 int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo_hit *hits, const TraceOpts &opt) {
@@ -143,6 +146,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     a.count_nodes = counting ? ctx->nodes : nullptr;
     const bool debug_hits = (ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE) && (ctx->uniforms.flags & SVO_F_SHOW_HITS);
     const bool stack = ctx->variant == SVO_VARIANT_STACK && !debug_hits;
+    a.shadow_hits = stack ? opt.shadow_out : nullptr;
     const uint32_t n_strips = (wd.n_items + 63u) / 64u;
     const bool schedule = ctx->schedule && n_strips <= svo::kMaxScheduledStrips;
     svo_ctx::Sched &sc = ctx->sched[opt.sched_slot & 1];
@@ -261,10 +265,33 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         if (rc) return rc;
         hits = (svo_hit *)ctx->shade_hits;
     }
-    rc = ensure_dev(ctx, &ctx->shade_aux, &ctx->shade_aux_bytes, n * sizeof(float));
-    if (rc) return rc;
+    // Shadow rays inside the primary launch: STACK variant, and a sun direction the fast arithmetic covers (it is the same
+    // for every shadow ray, so this is decided here; the origins are hit points inside the cube and always qualify).
+    // Automatic: where it measured faster -- deep trees (the shadow ray restarts from the primary ray's ancestor stack instead
+    // of descending from the root: depth-20 fractal -24 % at 1080p) and large frames (depth-16 terrain: -8 % at 4K, but +5 %
+    // at 1080p, where one lane's primary-plus-shadow chain lengthens the frame's tail more than the second launch costs).
+    const bool want_fused = ctx->fused_shadows == 1 ||
+                            (ctx->fused_shadows == 2 && (ctx->tree_depth > (uint32_t)svo::stack_max_depth(false) || n >= (1u << 22)));
+    bool fused = shadows && want_fused && ctx->variant == SVO_VARIANT_STACK;
+    if (fused) {
+        const float *sd = ctx->uniforms.sun_dir;
+        const float sl = sqrtf((sd[0] * sd[0] + sd[1] * sd[1]) + sd[2] * sd[2]);
+        for (int k = 0; k < 3; k++) {
+            float d = -(sd[k] / sl);
+            if (d == 0.0f) d = 0.000001f;  // octree_ray's bias, shader.wgsl:193-194
+            if (!(fabsf(d) >= 1.0e-11f && fabsf(d) <= 2.0f)) fused = false;  // (also NaN); the kernel needs 2^-40 <= |d| <= 2^40
+        }
+    }
     TraceOpts primary;
-    primary.aux_t = (float *)ctx->shade_aux;
+    if (fused) {
+        rc = ensure_dev(ctx, &ctx->shade_shadow, &ctx->shade_shadow_bytes, n * sizeof(svo_hit));
+        if (rc) return rc;
+        primary.shadow_out = (svo_hit *)ctx->shade_shadow;
+    } else {
+        rc = ensure_dev(ctx, &ctx->shade_aux, &ctx->shade_aux_bytes, n * sizeof(float));
+        if (rc) return rc;
+        primary.aux_t = (float *)ctx->shade_aux;
+    }
     rc = trace_launch(ctx, work, nullptr, hits, primary);
     if (rc) return rc;
     svo::TraceArgs a{};
@@ -273,7 +300,7 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     a.u = ctx->uniforms;
     a.work = work;
     a.hits = hits;
-    if (shadows) {
+    if (shadows && !fused) {
         rc = ensure_dev(ctx, &ctx->shade_rays, &ctx->shade_rays_bytes, n * 6 * sizeof(float));
         if (rc) return rc;
         rc = ensure_dev(ctx, &ctx->shade_shadow, &ctx->shade_shadow_bytes, n * sizeof(svo_hit));
@@ -498,6 +525,10 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
         case SVO_OPT_SCAN_CLEARS_COUNTERS:
             ctx->scan_clears = value != 0;
             return SVO_OK;
+        case SVO_OPT_FUSED_SHADOWS:
+            if (value < 0 || value > 2) return fail(ctx, SVO_ERR_ARG, "fused shadows: 0 (off), 1 (on) or 2 (automatic)");
+            ctx->fused_shadows = (int)value;
+            return SVO_OK;
         case SVO_OPT_STRIP_ITEMS:
             if (value < 64 || value > 2048 || (value & 63)) return fail(ctx, SVO_ERR_ARG, "strip_items must be a multiple of 64 in [64, 2048]");
             ctx->strip_items = (uint32_t)value;
@@ -543,6 +574,10 @@ int svo_sync(svo_ctx *ctx) {
     // surface device-side errors raised by trace kernels
     uint32_t st = 0;
     HIP_TRY(ctx, hipMemcpy(&st, ctx->status, sizeof(st), hipMemcpyDeviceToHost));
+    if (st & 2u) {
+        HIP_TRY(ctx, hipMemset(ctx->status, 0, sizeof(uint32_t)));
+        return fail(ctx, SVO_ERR_STATE, "fused shadow ray outside the range of the fast arithmetic (set SVO_OPT_FUSED_SHADOWS to 0)");
+    }
     if (st & 1u) {
         HIP_TRY(ctx, hipMemset(ctx->status, 0, sizeof(uint32_t)));
         return fail(ctx, SVO_ERR_STATE,

@@ -53,6 +53,8 @@ struct TraceArgs {
     uint32_t order_cap;         // entries reserved per list
     uint32_t *debug;            // optional: 8 words per wave (start, queue-dry, end ticks of 10 ns, rounds, active-lane sum, ...)
     const uint8_t *skip;        // mode 2, optional: one byte per ray; non-zero = no ray here, its (all-zero) record is already written
+    svo_hit *shadow_hits;       // STACK, optional (fused shadow rays): the lane that finishes a primary ray with a hit goes on with that
+                                // pixel's shadow ray (shader.wgsl:275-280) and writes its record here; pixels without one get zeros
 };
 
 struct LaunchInfo {

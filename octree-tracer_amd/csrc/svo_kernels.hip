@@ -124,6 +124,29 @@ __device__ __forceinline__ void write_hit(svo_hit *hits, uint32_t out, uint32_t 
     reinterpret_cast<uint4 *>(hits)[out] = rec;
 }
 
+__device__ __forceinline__ float code_to_normal(uint32_t c) { return c == 1u ? 1.0f : (c == 2u ? -1.0f : 0.0f); }
+
+// normalize(u.sun_dir.xyz), shader.wgsl:275
+__device__ __forceinline__ void sun_direction(const svo_uniforms &u, float s[3]) {
+    const float sl = sqrtf((u.sun_dir[0] * u.sun_dir[0] + u.sun_dir[1] * u.sun_dir[1]) + u.sun_dir[2] * u.sun_dir[2]);
+    s[0] = u.sun_dir[0] / sl; s[1] = u.sun_dir[1] / sl; s[2] = u.sun_dir[2] / sl;
+}
+
+// Where the secondary rays of a hit start (shader.wgsl:276): HitInfo.pos + normal * 2.5e-6, with HitInfo.pos the
+// voxel_pos of the last step (the entry point when no step was taken) rebuilt from the primary ray (pos, dir: after
+// ray_enter), the record's step count and normal codes, and t_current of the last step.
+__device__ __forceinline__ void secondary_origin(const float pos[3], const float dir[3], uint32_t steps, uint32_t ncode, float t,
+                                                 float org[3], float n[3]) {
+    n[0] = code_to_normal(ncode & 3u); n[1] = code_to_normal((ncode >> 2) & 3u); n[2] = code_to_normal((ncode >> 4) & 3u);
+    float h0 = pos[0], h1 = pos[1], h2 = pos[2];
+    if (steps != 0u) {
+        h0 = pos[0] + dir[0] * t - n[0] * 0.000002f;
+        h1 = pos[1] + dir[1] * t - n[1] * 0.000002f;
+        h2 = pos[2] + dir[2] * t - n[2] * 0.000002f;
+    }
+    org[0] = h0 + n[0] * 0.0000025f; org[1] = h1 + n[1] * 0.0000025f; org[2] = h2 + n[2] * 0.0000025f;
+}
+
 struct Item {
     bool valid;
     uint32_t out, px, py;
@@ -215,18 +238,16 @@ __device__ __forceinline__ void count_visit(uint32_t *nodes, uint32_t n_words, u
     if (n) count_add(nodes, p, word, n);
 }
 
-__device__ __forceinline__ void trace_one_restart(const TraceArgs &a, rsrc_t rs, bool misc_bool, bool counter_hits,
-                                                  uint32_t q) {
+// One ray, the reference's way.  `hits[out]` receives the record, `aux` (optional) t_current of the last step, and the
+// return value is that t_current as well (the fused-shadow post pass builds the shadow ray of a deferred primary ray from it).
+__device__ __forceinline__ float trace_ray_restart(const TraceArgs &a, rsrc_t rs, bool misc_bool, bool counter_hits, const RayIn &r,
+                                                   svo_hit *hits, uint32_t out, float *aux) {
     const bool count = a.count_nodes != nullptr;
-    Item it = decode_item(a.work, q);
-    if (!it.valid) return;
-    if (a.work.mode == 2 && a.skip && a.skip[q]) return;  // no ray: the producer wrote the record
-    RayIn r = item_ray(a, it);
     float pos[3], dir[3], dist;
     if (!ray_enter(r, pos, dir, dist)) {
-        write_hit(a.hits, it.out, 0u, 0.0f, 0u, 0u, 0u, 0u);
-        if (a.aux_t) a.aux_t[it.out] = 0.0f;
-        return;
+        write_hit(hits, out, 0u, 0.0f, 0u, 0u, 0u, 0u);
+        if (aux) aux[out] = 0.0f;
+        return 0.0f;
     }
     float rs0 = sign_w(dir[0]), rs1 = sign_w(dir[1]), rs2 = sign_w(dir[2]);
     float vp0 = pos[0], vp1 = pos[1], vp2 = pos[2];
@@ -259,15 +280,15 @@ __device__ __forceinline__ void trace_one_restart(const TraceArgs &a, rsrc_t rs,
         }
         uint32_t nc = normal_code(n0) | (normal_code(n1) << 2) | (normal_code(n2) << 4);
         if (overflow) {
-            write_hit(a.hits, it.out, 0xFF000000u, dist + t_current, steps, 100u, 1u, nc);
-            if (a.aux_t) a.aux_t[it.out] = t_current;
-            return;
+            write_hit(hits, out, 0xFF000000u, dist + t_current, steps, 100u, 1u, nc);
+            if (aux) aux[out] = t_current;
+            return t_current;
         }
         bool solid = counter_hits ? ((word & 15u) > 0u) : (((word >> 4) - kVoxelOffset) > 0u);
         if (solid) {
-            write_hit(a.hits, it.out, p, dist + t_current, steps, depth, 1u, nc);
-            if (a.aux_t) a.aux_t[it.out] = t_current;
-            return;
+            write_hit(hits, out, p, dist + t_current, steps, depth, 1u, nc);
+            if (aux) aux[out] = t_current;
+            return t_current;
         }
         float voxel_size = 2.0f / (float)(1u << depth);
         float t0 = (c0 - pos[0] + rs0 * voxel_size / 2.0f) / dir[0];
@@ -282,18 +303,26 @@ __device__ __forceinline__ void trace_one_restart(const TraceArgs &a, rsrc_t rs,
         vp1 = pos[1] + dir[1] * t_current - n1 * 0.000002f;
         vp2 = pos[2] + dir[2] * t_current - n2 * 0.000002f;
         if (!in_bounds(vp0, vp1, vp2)) {
-            write_hit(a.hits, it.out, 0x20202000u, dist + t_current, steps, depth, 0u, 0u);
-            if (a.aux_t) a.aux_t[it.out] = t_current;
-            return;
+            write_hit(hits, out, 0x20202000u, dist + t_current, steps, depth, 0u, 0u);
+            if (aux) aux[out] = t_current;
+            return t_current;
         }
         steps += 1;
         if (steps > 100u) {
-            write_hit(a.hits, it.out, 0xFF000000u, dist + t_current, steps, 100u, 1u,
+            write_hit(hits, out, 0xFF000000u, dist + t_current, steps, 100u, 1u,
                       normal_code(n0) | (normal_code(n1) << 2) | (normal_code(n2) << 4));
-            if (a.aux_t) a.aux_t[it.out] = t_current;
-            return;
+            if (aux) aux[out] = t_current;
+            return t_current;
         }
     }
+}
+
+
+__device__ __forceinline__ float trace_one_restart(const TraceArgs &a, rsrc_t rs, bool misc_bool, bool counter_hits, uint32_t q) {
+    Item it = decode_item(a.work, q);
+    if (!it.valid) return 0.0f;
+    if (a.work.mode == 2 && a.skip && a.skip[q]) return 0.0f;  // no ray: the producer wrote the record
+    return trace_ray_restart(a, rs, misc_bool, counter_hits, item_ray(a, it), a.hits, it.out, a.aux_t);
 }
 
 // list == nullptr: every item of the work description; else the items list[1 .. list[0]] (rays the
@@ -460,6 +489,7 @@ __device__ __forceinline__ bool clean_component(float p, float d) {
 // normal) | 16 normal-is-entry-normal | 31 active | 30 needs descent (only ever set together with active) | 21 record pending | 22..24 how it ended
 constexpr uint32_t ST_L_SHIFT = 8, ST_M_SHIFT = 13, ST_SAT_SHIFT = 25;  // bits 25..29: see step 3a (counting instantiation)
 constexpr uint32_t ST_ENTRY = 1u << 16, ST_ACTIVE = 1u << 31, ST_DESC = 1u << 30;
+constexpr uint32_t ST_SHADOW = 1u << 17;  // SHD instantiation: the lane traces the shadow ray of the pixel in `out`
 // a finished ray keeps its state until the lane is refilled: record not yet written + how it ended
 constexpr uint32_t ST_PENDING = 1u << 21, ST_F_TOODEEP = 1u << 22, ST_F_SOLID = 1u << 23, ST_F_INB = 1u << 24;
 constexpr uint32_t ST_L_MASK = 31u << ST_L_SHIFT, ST_M_MASK = 7u << ST_M_SHIFT;
@@ -478,7 +508,7 @@ constexpr int kPoolWords = 11;
 // a clean ray), so  A = (C - P) + H,  t = A / Dr,  G = (P + Dr * t) +- K  are exactly 2^23 times the
 // reference's  a,  the same t,  and  2^23 * voxel_pos  -- and G is what the path codes need.
 // CNT: hit counters live (adaptive mode, shader.wgsl:157-161), see step 3a in the loop.
-template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT>
+template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD>
 __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
@@ -487,6 +517,20 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
     static_assert(SMAX <= D - 1, "stack deeper than the path codes");
     constexpr int TBL = 1 << (3 * K);
     constexpr float kScale = 8388608.0f;  // 2^23
+    constexpr float kInvScale = 1.0f / 8388608.0f;
+    // SHD: direction of every shadow ray, -normalize(sun_dir) (wave-uniform, kept in scalar registers)
+    float shadow_d0 = 0.0f, shadow_d1 = 0.0f, shadow_d2 = 0.0f;
+    float sDr0 = 1.0f, sDr1 = 1.0f, sDr2 = 1.0f, sY0 = 1.0f, sY1 = 1.0f, sY2 = 1.0f;  // what ray_enter and the pick-up make of it
+    if (SHD) {
+        auto uni = [](float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); };
+        float sun[3];
+        sun_direction(a.u, sun);
+        shadow_d0 = uni(-sun[0]); shadow_d1 = uni(-sun[1]); shadow_d2 = uni(-sun[2]);
+        sDr0 = uni((shadow_d0 + ((shadow_d0 == 0.0f) ? 1.0f : 0.0f) * 0.000001f) * kScale);  // octree_ray's bias (ray_enter), then grid units
+        sDr1 = uni((shadow_d1 + ((shadow_d1 == 0.0f) ? 1.0f : 0.0f) * 0.000001f) * kScale);
+        sDr2 = uni((shadow_d2 + ((shadow_d2 == 0.0f) ? 1.0f : 0.0f) * 0.000001f) * kScale);
+        sY0 = uni(1.0f / sDr0); sY1 = uni(1.0f / sDr1); sY2 = uni(1.0f / sDr2);
+    }
     extern __shared__ uint32_t lds[];
     uint32_t *tbl = lds;                          // TBL entries
     uint32_t *stk = lds + TBL;                    // [NS][BLOCK]
@@ -597,7 +641,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
     };
 
     // write the record of a finished ray (deferred to the next refill so that it runs for many lanes at once)
-    auto flush_record = [&]() {
+    auto flush_record = [&](bool may_continue) {
         const bool too_deep = (st & ST_F_TOODEEP) != 0u, solid = (st & ST_F_SOLID) != 0u, inb = (st & ST_F_INB) != 0u;
         const bool stop_here = too_deep || solid;
         const uint32_t L = (st >> ST_L_SHIFT) & 31u, nm = (st >> ST_M_SHIFT) & 7u;
@@ -608,8 +652,58 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
         const uint32_t value = too_deep ? 0xFF000000u : (solid ? (leaf_off >> 2) : (!inb ? 0x20202000u : 0xFF000000u));
         const uint32_t depth = (too_deep || (!solid && inb)) ? 100u : L;
         const uint32_t hit = (stop_here || inb) ? 1u : 0u;
-        write_hit(a.hits, out & 0x03FFFFFFu, value, dist + tcur, st & 0xFFu, depth, hit, ncode);
-        if (a.aux_t) a.aux_t[out & 0x03FFFFFFu] = tcur;
+        const bool was_shadow = SHD && (st & ST_SHADOW) != 0u;
+        write_hit(was_shadow ? a.shadow_hits : a.hits, out & 0x03FFFFFFu, value, dist + tcur, st & 0xFFu, depth, hit, ncode);
+        if (a.aux_t && !was_shadow) a.aux_t[out & 0x03FFFFFFu] = tcur;
+        if (SHD && !was_shadow) {
+            // fs_main's shadow ray (shader.wgsl:275-280), on the lane that found the hit: same arithmetic as
+            // secondary_gen_kernel (the primary ray's entry point and direction are P, Dr scaled by 2^23, exactly), and the
+            // descent restarts from the ancestors this lane already holds instead of from the root.
+            bool go = false;
+            float pos2[3], dir2[3], d2 = 0.0f;
+            if (may_continue && hit) {
+                const float pw[3] = {P0 * kInvScale, P1 * kInvScale, P2 * kInvScale};
+                const float dw[3] = {Dr0 * kInvScale, Dr1 * kInvScale, Dr2 * kInvScale};
+                float org[3], nrm[3];
+                secondary_origin(pw, dw, st & 0xFFu, ncode, tcur, org, nrm);
+                if (in_bounds(org[0], org[1], org[2])) {  // ray_enter's common case: the ray starts where it is
+                    pos2[0] = org[0]; pos2[1] = org[1]; pos2[2] = org[2];
+                    go = true;
+                } else {  // a hit on the cube's surface with the normal pointing out: the whole of ray_enter
+                    const RayIn r = {org[0], org[1], org[2], shadow_d0, shadow_d1, shadow_d2};
+                    go = ray_enter(r, pos2, dir2, d2);
+                }
+                if (go && !(fabsf(pos2[0]) <= 2.0f && fabsf(pos2[1]) <= 2.0f && fabsf(pos2[2]) <= 2.0f && fabsf(d2) <= 1.0e30f)) {
+                    // cannot happen for an origin next to a hit inside the cube (the host checked the direction); reported by svo_sync
+                    atomicOr(a.status, 2u);
+                    go = false;
+                }
+            }
+            if (go) {
+                const uint32_t L_old = (st >> ST_L_SHIFT) & 31u, sat_old = (st >> ST_SAT_SHIFT) & 31u;
+                P0 = pos2[0] * kScale; P1 = pos2[1] * kScale; P2 = pos2[2] * kScale;
+                Dr0 = sDr0; Dr1 = sDr1; Dr2 = sDr2;  // the same for every shadow ray
+                Y0 = sY0; Y1 = sY1; Y2 = sY2;
+                K0 = copysign_bits(0.000002f * 8388608.0f, Dr0);
+                K1 = copysign_bits(0.000002f * 8388608.0f, Dr1);
+                K2 = copysign_bits(0.000002f * 8388608.0f, Dr2);
+                dist = d2;
+                tcur = 0.0f;
+                const uint32_t ecode = normal_code(truncf(pos2[0] * 1.000001f)) | (normal_code(truncf(pos2[1] * 1.000001f)) << 2) |
+                                       (normal_code(truncf(pos2[2] * 1.000001f)) << 4);
+                out = (out & 0x03FFFFFFu) | (ecode << 26);
+                const int32_t jx = entry_code<GE>(P0), jy = entry_code<GE>(P1), jz = entry_code<GE>(P2);
+                const uint32_t diff = (uint32_t)((ix ^ jx) | (iy ^ jy) | (iz ^ jz));
+                const uint32_t c = (uint32_t)__clz((int)((diff << 8) | 0x80u));  // levels the old and the new path share
+                ix = jx; iy = jy; iz = jz;
+                const uint32_t r = max(min(min(c + 1u, L_old), (uint32_t)SMAX), 1u);
+                st = ST_ACTIVE | ST_DESC | ST_ENTRY | ST_SHADOW;
+                if (CNT) st |= min(sat_old, r - 1u) << ST_SAT_SHIFT;
+                restart_at(r);
+                return;
+            }
+            reinterpret_cast<uint4 *>(a.shadow_hits)[out & 0x03FFFFFFu] = make_uint4(0u, 0u, 0u, 0u);  // no shadow ray: the record of a ray that never enters
+        }
         st = 0u;
     };
 
@@ -667,6 +761,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                             if (!ray_enter(r, pos, dir, gdist)) {
                                 write_hit(a.hits, it.out, 0u, 0.0f, 0u, 0u, 0u, 0u);
                                 if (a.aux_t) a.aux_t[it.out] = 0.0f;
+                                if (SHD) reinterpret_cast<uint4 *>(a.shadow_hits)[it.out] = make_uint4(0u, 0u, 0u, 0u);
                             } else if (!(clean_component(pos[0], dir[0]) && clean_component(pos[1], dir[1]) &&
                                          clean_component(pos[2], dir[2]) && fabsf(gdist) <= 1.0e30f)) {
                                 // outside the proven range of the fast arithmetic: hand the ray to the
@@ -718,7 +813,8 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                     if (DBG && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
                 }
                 // -- idle lanes first write the record of the ray they finished, then take rays pool_i .. --
-                if (st & ST_PENDING) flush_record();
+                if (st & ST_PENDING) flush_record(true);
+                if (SHD) act = __ballot((int32_t)st < 0);  // lanes that went on with a shadow ray are not idle
                 if (!(st & ST_ACTIVE)) {
                     const uint64_t idle = ~act;
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
@@ -748,9 +844,13 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                         restart_at(1u);
                     }
                 }
-                const uint32_t took = min(n_idle, pool_n);
+                const uint32_t took = min(SHD ? 64u - (uint32_t)__popcll(act) : n_idle, pool_n);
                 pool_i += took;
                 pool_n -= took;
+                act = __ballot((int32_t)st < 0);
+            }
+            if (SHD && !more) {  // nothing left to hand out, but finished primary rays still have their shadow rays to trace
+                if (st & ST_PENDING) flush_record(true);
                 act = __ballot((int32_t)st < 0);
             }
             // the only exit: nothing in flight, nothing pooled, nothing left to claim.  (No lane active but work left --
@@ -906,7 +1006,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
         for (int o = 32; o > 0; o >>= 1) last = max(last, (uint32_t)__shfl_xor((int)last, o));
         dbg_iters = last;
     }
-    if (st & ST_PENDING) flush_record();
+    if (st & ST_PENDING) flush_record(false);
     if (DBG && lane == 0) {
         uint64_t t_end = __builtin_amdgcn_s_memrealtime();
         uint32_t *d = a.debug + 8u * wave_id;
@@ -1042,15 +1142,37 @@ __global__ __launch_bounds__(256) void post_kernel(TraceArgs a, uint32_t *claim_
         if (threadIdx.x == 0) *next_deferred_count = 0u;
     }
     const uint32_t n_def = list[0];
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_def; i += gridDim.x * 256u)
-        trace_one_restart(a, rs, misc_bool, false, list[1u + i]);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_def; i += gridDim.x * 256u) {
+        const uint32_t q = list[1u + i];
+        const float t = trace_one_restart(a, rs, misc_bool, false, q);
+        if (a.shadow_hits) {  // fused shadow rays: the deferred primary ray's shadow ray, the same way
+            const Item it = decode_item(a.work, q);
+            const uint4 rec = reinterpret_cast<const uint4 *>(a.hits)[it.out];
+            bool traced = false;
+            if ((rec.z >> 16) & 1u) {
+                float pos[3], dir[3], dist, org[3], nrm[3], sun[3];
+                if (ray_enter(item_ray(a, it), pos, dir, dist)) {
+                    secondary_origin(pos, dir, rec.z & 0xFFu, rec.w, t, org, nrm);
+                    sun_direction(a.u, sun);
+                    const RayIn r = {org[0], org[1], org[2], -sun[0], -sun[1], -sun[2]};
+                    trace_ray_restart(a, rs, misc_bool, false, r, a.shadow_hits, it.out, nullptr);
+                    traced = true;
+                }
+            }
+            if (!traced) reinterpret_cast<uint4 *>(a.shadow_hits)[it.out] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
     if (cost) {
         const uint32_t lane = threadIdx.x & 63u;
         const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = gridDim.x * 4u;
         for (uint32_t s = wave; s < n_strips; s += n_waves) {
             ItemFast it = decode_item_fast(a.work, s * 64u + lane);
             uint32_t steps = 0;
-            if (it.valid) steps = reinterpret_cast<const uint4 *>(a.hits)[it.out].z & 0xFFu;
+            if (it.valid) {
+                steps = reinterpret_cast<const uint4 *>(a.hits)[it.out].z & 0xFFu;
+                // fused shadow rays: the lane's chain is the primary ray plus its shadow ray
+                if (a.shadow_hits) steps += reinterpret_cast<const uint4 *>(a.shadow_hits)[it.out].z & 0xFFu;
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, o));
             if (lane == 0) cost[s] = (uint8_t)min(steps >> 3, 15u);  // cost class
@@ -1176,8 +1298,6 @@ __global__ __launch_bounds__(kOrderThreads) void strip_order_kernel(const uint8_
 // pixel (a ray that starts outside the cube pointing away -- an immediate miss -- for pixels that need none),
 // the trace kernel produces a second set of records, and shade_kernel combines both into RGBA8.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float code_to_normal(uint32_t c) { return c == 1u ? 1.0f : (c == 2u ? -1.0f : 0.0f); }
-
 // Directions of the extra secondary rays (benchmark config 5; the reference itself only has the shadow ray):
 // three 10-bit fields of an integer hash of (frame pixel id, k) as half-integer components in (-512, 512),
 // normalised like every other direction, mirrored into the hemisphere of the hit normal.  Integer -> float
@@ -1189,8 +1309,9 @@ __device__ __forceinline__ uint32_t mix32(uint32_t a) {
 
 __global__ __launch_bounds__(256) void secondary_gen_kernel(TraceArgs a, const float *aux_t, float *rays, uint8_t *skip, svo_hit *out,
                                                             uint32_t n_secondary, uint32_t n_records) {
-    const float sl = sqrtf((a.u.sun_dir[0] * a.u.sun_dir[0] + a.u.sun_dir[1] * a.u.sun_dir[1]) + a.u.sun_dir[2] * a.u.sun_dir[2]);
-    const float s0 = a.u.sun_dir[0] / sl, s1 = a.u.sun_dir[1] / sl, s2 = a.u.sun_dir[2] / sl;  // normalize(u.sun_dir.xyz)
+    float sun[3];
+    sun_direction(a.u, sun);
+    const float s0 = sun[0], s1 = sun[1], s2 = sun[2];
     const uint32_t width = (uint32_t)a.u.dimensions[0];
     for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < a.work.n_items; q += gridDim.x * 256u) {
         Item it = decode_item(a.work, q);
@@ -1210,15 +1331,9 @@ __global__ __launch_bounds__(256) void secondary_gen_kernel(TraceArgs a, const f
         RayIn r = gen_ray(a.u, it.px, it.py);
         float pos[3], dir[3], dist;
         ray_enter(r, pos, dir, dist);
-        const float n0 = code_to_normal(rec.w & 3u), n1 = code_to_normal((rec.w >> 2) & 3u), n2 = code_to_normal((rec.w >> 4) & 3u);
-        float h0 = pos[0], h1 = pos[1], h2 = pos[2];  // HitInfo.pos = voxel_pos of the last find_voxel
-        if ((rec.z & 0xFFu) != 0u) {
-            const float t = aux_t[it.out];
-            h0 = pos[0] + dir[0] * t - n0 * 0.000002f;
-            h1 = pos[1] + dir[1] * t - n1 * 0.000002f;
-            h2 = pos[2] + dir[2] * t - n2 * 0.000002f;
-        }
-        const float org[3] = {h0 + n0 * 0.0000025f, h1 + n1 * 0.0000025f, h2 + n2 * 0.0000025f};  // :276
+        float org[3], nrm[3];
+        secondary_origin(pos, dir, rec.z & 0xFFu, rec.w, (rec.z & 0xFFu) != 0u ? aux_t[it.out] : 0.0f, org, nrm);
+        const float n0 = nrm[0], n1 = nrm[1], n2 = nrm[2];
         for (uint32_t k = 0; k < n_secondary; k++) {
             float d0, d1, d2;
             if (k == 0u) {
@@ -1337,13 +1452,16 @@ int stack_max_depth(bool deep) { return kTopLevels + 1 + (deep ? kStackLevelsDee
 template <bool GE, int NS>
 static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
     const uint32_t strip_items = args.order ? 64u : (li.strip_items ? li.strip_items : 64u);
-    auto kern = args.count_nodes ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true>
-                                 : (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false>
-                                               : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false>);
+    const bool shd = args.shadow_hits != nullptr;  // fused shadow rays (no timeline build of that one)
+    auto kern = shd ? (args.count_nodes ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, true>
+                                        : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, true>)
+                    : (args.count_nodes ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, false>
+                                        : (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false>
+                                                      : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false>));
     size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
                                 (args.count_nodes ? kTopAuxEntries : 0)) * sizeof(uint32_t);
-    static int occupancy[2] = {0, 0};  // [counting instantiation?]
-    int &blocks_per_cu = occupancy[args.count_nodes ? 1 : 0];
+    static int occupancy[4] = {0, 0, 0, 0};  // [fused shadows?][counting instantiation?]
+    int &blocks_per_cu = occupancy[(shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
     if (blocks_per_cu == 0) {
         int n = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kStackBlock, lds_bytes);

@@ -413,6 +413,50 @@ def test_shaded_frame_counts_shadow_rays(pkg, gpu, O, small_words, variant):
     assert np.array_equal(render.read_nodes(small_words.size), O.count_frame(small_words, u))
 
 
+def test_fused_shadow_rays_match_two_pass(pkg, gpu, O, monu9_words, small_words):
+    """SVO_OPT_FUSED_SHADOWS: the shadow ray of a hit traced by the lane that found it, inside the primary launch, against
+    the two-launch form (generator + explicit rays): identical images, identical records, and -- with live counters --
+    identical node arrays; also inside the cube, with the >= tie-break, a sun along an axis (zero components get
+    octree_ray's bias) and on a deep tree."""
+    gpu.set_option(pkg.gpu.OPT_VARIANT, pkg.gpu.VARIANT_STACK)
+    terrain = pkg.scenes.terrain(seed=3, max_depth=13, cam=(0.2, 0.6, -0.7), lod_c=300.0, max_words=6_000_000)
+    cases = [
+        (monu9_words, O.F_PAUSE_ADAPTIVE | O.F_SHADOWS, ((0.1, 0.2, -1.5), (0.0, 0.0, 1.5)), None),
+        (monu9_words, O.F_PAUSE_ADAPTIVE | O.F_SHADOWS | O.F_MISC_BOOL, ((0.02, 0.31, 0.05), (0.3, -0.2, 1.0)), None),
+        (monu9_words, O.F_PAUSE_ADAPTIVE | O.F_SHADOWS, ((1.3, 0.9, 1.2), (-1.0, -0.6, -1.0)), (0.0, -1.0, 0.0)),
+        (monu9_words, O.F_SHADOWS, ((0.1, 0.2, -1.5), (0.0, 0.0, 1.5)), None),              # counters live
+        (small_words, O.F_SHADOWS, ((0.1, 0.2, -1.5), (0.0, 0.0, 1.5)), (1.0, -0.3, 0.0)),
+        (terrain, O.F_PAUSE_ADAPTIVE | O.F_SHADOWS, ((0.2, 0.6, -0.7), (0.1, -0.5, 1.0)), None),
+        (terrain, O.F_SHADOWS, ((0.2, 0.6, -0.7), (0.1, -0.5, 1.0)), (-0.4, -1.0, 0.3)),
+    ]
+    # last case: every primary ray has a direction component of 1e-30 -- outside the range of the fast arithmetic, so the
+    # whole frame (and its shadow rays) goes through the deferred list of the post pass
+    cases.append((monu9_words, O.F_PAUSE_ADAPTIVE | O.F_SHADOWS, ((0.0, 0.0, -1.5), (0.0, 0.0, 1.5)), (-0.3, -1.0, 0.2)))
+    for case, (words, flags, pose, sun) in enumerate(cases):
+        u = O.make_uniforms(pos=pose[0], look=pose[1], width=320, height=200, flags=flags)
+        if sun is not None:
+            u.sun_dir[:3] = list(sun)
+        if case == len(cases) - 1:
+            u.camera_inverse[0] *= 1e-30
+        results = []
+        for fused in (1, 0):
+            gpu.set_option(pkg.gpu.OPT_FUSED_SHADOWS, fused)
+            render = pkg.Render(gpu, (320, 200), words, capacity=words.size)
+            set_uniforms_from_oracle(render, u)
+            for frame in range(2):  # second frame: schedules in place, counters carried over
+                hits, img = render.render_host(rgba=True)
+            results.append((hits, img, render.read_nodes(words.size)))
+        gpu.set_option(pkg.gpu.OPT_FUSED_SHADOWS, 2)  # back to the default (automatic)
+        (h1, i1, n1), (h0, i0, n0) = results
+        what = f"flags={flags} sun={sun} words={words.size}"
+        assert_hits_equal(h1, h0, "fused vs two-pass records, " + what)
+        assert np.array_equal(i1, i0), "fused vs two-pass image, " + what
+        assert np.array_equal(n1, n0), "fused vs two-pass counters, " + what
+        assert (i1[..., :3].reshape(-1, 3).max(axis=1) > 0).mean() > 0.1, what
+        if case == len(cases) - 1:
+            assert ((h1["info"] >> 16) & 1).sum() > 100, "the deferred frame should hit the model"
+
+
 def test_adaptive_streaming_loop(pkg, gpu, O, monu9_words):
     """The reference's frame loop with live counters (app.rs:94-118 + adaptive.rs): starting from the 8-word
     root tree, hot leaves are subdivided from the CPU world and the device tree converges towards the view;
