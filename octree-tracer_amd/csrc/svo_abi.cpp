@@ -237,6 +237,25 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     return SVO_OK;
 }
 
+// Shadow rays inside the primary launch?  STACK variant, a sun direction the fast arithmetic covers (it is the same for every
+// shadow ray, so this is decided here; the origins are hit points inside the cube and always qualify), and -- in automatic
+// mode -- where it measured faster: deep trees (the shadow ray restarts from the primary ray's ancestor stack instead of
+// descending from the root: depth-20 fractal -24 % at 1080p) and large frames (depth-16 terrain: -8 % at 4K, but +5 % at
+// 1080p, where one lane's primary-plus-shadow chain lengthens the frame's tail more than the second launch costs).
+bool fuse_shadow_rays(const svo_ctx *ctx, size_t n_pixels) {
+    const bool want = ctx->fused_shadows == 1 ||
+                      (ctx->fused_shadows == 2 && (ctx->tree_depth > (uint32_t)svo::stack_max_depth(false) || n_pixels >= (1u << 22)));
+    if (!want || ctx->variant != SVO_VARIANT_STACK) return false;
+    const float *sd = ctx->uniforms.sun_dir;
+    const float sl = sqrtf((sd[0] * sd[0] + sd[1] * sd[1]) + sd[2] * sd[2]);
+    for (int k = 0; k < 3; k++) {
+        float d = -(sd[k] / sl);
+        if (d == 0.0f) d = 0.000001f;  // octree_ray's bias, shader.wgsl:193-194
+        if (!(fabsf(d) >= 1.0e-11f && fabsf(d) <= 2.0f)) return false;  // (also NaN); the kernel needs 2^-40 <= |d| <= 2^40
+    }
+    return true;
+}
+
 int ensure_dev(svo_ctx *ctx, void **buf, size_t *have, size_t bytes) {
     if (*have >= bytes) return SVO_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -265,23 +284,7 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         if (rc) return rc;
         hits = (svo_hit *)ctx->shade_hits;
     }
-    // Shadow rays inside the primary launch: STACK variant, and a sun direction the fast arithmetic covers (it is the same
-    // for every shadow ray, so this is decided here; the origins are hit points inside the cube and always qualify).
-    // Automatic: where it measured faster -- deep trees (the shadow ray restarts from the primary ray's ancestor stack instead
-    // of descending from the root: depth-20 fractal -24 % at 1080p) and large frames (depth-16 terrain: -8 % at 4K, but +5 %
-    // at 1080p, where one lane's primary-plus-shadow chain lengthens the frame's tail more than the second launch costs).
-    const bool want_fused = ctx->fused_shadows == 1 ||
-                            (ctx->fused_shadows == 2 && (ctx->tree_depth > (uint32_t)svo::stack_max_depth(false) || n >= (1u << 22)));
-    bool fused = shadows && want_fused && ctx->variant == SVO_VARIANT_STACK;
-    if (fused) {
-        const float *sd = ctx->uniforms.sun_dir;
-        const float sl = sqrtf((sd[0] * sd[0] + sd[1] * sd[1]) + sd[2] * sd[2]);
-        for (int k = 0; k < 3; k++) {
-            float d = -(sd[k] / sl);
-            if (d == 0.0f) d = 0.000001f;  // octree_ray's bias, shader.wgsl:193-194
-            if (!(fabsf(d) >= 1.0e-11f && fabsf(d) <= 2.0f)) fused = false;  // (also NaN); the kernel needs 2^-40 <= |d| <= 2^40
-        }
-    }
+    const bool fused = shadows && fuse_shadow_rays(ctx, n);
     TraceOpts primary;
     if (fused) {
         rc = ensure_dev(ctx, &ctx->shade_shadow, &ctx->shade_shadow_bytes, n * sizeof(svo_hit));
@@ -308,7 +311,7 @@ int trace_common(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         rc = ensure_dev(ctx, &ctx->shade_skip, &ctx->shade_skip_bytes, n);
         if (rc) return rc;
         HIP_TRY(ctx, svo::launch_secondary_gen(a, (const float *)ctx->shade_aux, (float *)ctx->shade_rays, (uint8_t *)ctx->shade_skip,
-                                               (svo_hit *)ctx->shade_shadow, 1u, (uint32_t)n, ctx->stream));
+                                               (svo_hit *)ctx->shade_shadow, 0u, 1u, (uint32_t)n, ctx->stream));
         svo::WorkDesc rw{};
         rw.mode = 2;
         rw.n_items = (uint32_t)n;
@@ -343,10 +346,16 @@ int trace_secondary(svo_ctx *ctx, const svo::WorkDesc &work, uint32_t n_secondar
     if (rc) return rc;
     rc = ensure_dev(ctx, &ctx->shade_rays, &ctx->shade_rays_bytes, n * n_secondary * 6 * sizeof(float));
     if (rc) return rc;
+    // ray 0, the shadow ray, can run inside the primary launch (its records go straight to the first set)
+    const bool debug_view = (ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE) && (ctx->uniforms.flags & SVO_F_SHOW_HITS);
+    const bool fused = !debug_view && fuse_shadow_rays(ctx, n);
+    const uint32_t k_first = fused ? 1u : 0u;
     TraceOpts popt;
     popt.aux_t = (float *)ctx->shade_aux;
+    if (fused) popt.shadow_out = secondary;
     rc = trace_launch(ctx, work, nullptr, primary, popt);
     if (rc) return rc;
+    if (k_first == n_secondary) return SVO_OK;
     svo::TraceArgs a{};
     a.nodes = ctx->nodes;
     a.n_words = (uint32_t)ctx->capacity;
@@ -355,17 +364,18 @@ int trace_secondary(svo_ctx *ctx, const svo::WorkDesc &work, uint32_t n_secondar
     a.hits = primary;
     rc = ensure_dev(ctx, &ctx->shade_skip, &ctx->shade_skip_bytes, n * n_secondary);
     if (rc) return rc;
-    HIP_TRY(ctx, svo::launch_secondary_gen(a, (const float *)ctx->shade_aux, (float *)ctx->shade_rays, (uint8_t *)ctx->shade_skip, secondary,
-                                           n_secondary, (uint32_t)n, ctx->stream));
+    svo_hit *rest = secondary + (size_t)k_first * n;
+    HIP_TRY(ctx, svo::launch_secondary_gen(a, (const float *)ctx->shade_aux, (float *)ctx->shade_rays, (uint8_t *)ctx->shade_skip, rest,
+                                           k_first, n_secondary, (uint32_t)n, ctx->stream));
     svo::WorkDesc rw{};
     rw.mode = 2;
-    rw.n_items = (uint32_t)(n * n_secondary);
+    rw.n_items = (uint32_t)(n * (n_secondary - k_first));
     rw.bpr = rw.bprect = rw.tiles_x = 1;
     TraceOpts sopt;
     sopt.count_rays = true;  // like the shadow ray, which passes primary = true (shader.wgsl:276)
     sopt.sched_slot = 1;
     sopt.skip = (const uint8_t *)ctx->shade_skip;
-    return trace_launch(ctx, rw, (const float *)ctx->shade_rays, secondary, sopt);
+    return trace_launch(ctx, rw, (const float *)ctx->shade_rays, rest, sopt);
 }
 
 int make_tiles_work(svo_ctx *ctx, uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t first_tile,

@@ -83,7 +83,8 @@ hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cos
 hipError_t launch_schedule_skipping(const uint8_t *skip, uint32_t n_items, const uint8_t *prev, uint8_t *cls, uint32_t *sched,
                                     uint32_t n_strips, uint32_t cap, hipStream_t stream);
 // secondary rays of the hit pixels of args.hits; pixels without a hit get skip = 1 and a zero record in `out` instead of a ray
-hipError_t launch_secondary_gen(const TraceArgs &args, const float *aux_t, float *rays, uint8_t *skip, svo_hit *out,
+// (rays k_first .. n_secondary - 1; slot of ray k of record r: (k - k_first) * n_records + r)
+hipError_t launch_secondary_gen(const TraceArgs &args, const float *aux_t, float *rays, uint8_t *skip, svo_hit *out, uint32_t k_first,
                                 uint32_t n_secondary, uint32_t n_records, hipStream_t stream);
 hipError_t launch_shade(const TraceArgs &args, const svo_hit *shadow_hits, uint32_t *rgba, hipStream_t stream);
 hipError_t launch_diag_gather(const uint32_t *buf, uint32_t n_words, uint32_t stride_words, uint32_t n_loads, uint32_t *sink,

@@ -1307,8 +1307,10 @@ __device__ __forceinline__ uint32_t mix32(uint32_t a) {
     return a;
 }
 
+// Rays k_first .. n_secondary-1 of every pixel (ray 0 is the shadow ray; with k_first = 1 it was traced inside the primary launch);
+// slot of ray k of record r: (k - k_first) * n_records + r, in `rays`, `skip` and `out` alike.
 __global__ __launch_bounds__(256) void secondary_gen_kernel(TraceArgs a, const float *aux_t, float *rays, uint8_t *skip, svo_hit *out,
-                                                            uint32_t n_secondary, uint32_t n_records) {
+                                                            uint32_t k_first, uint32_t n_secondary, uint32_t n_records) {
     float sun[3];
     sun_direction(a.u, sun);
     const float s0 = sun[0], s1 = sun[1], s2 = sun[2];
@@ -1321,8 +1323,8 @@ __global__ __launch_bounds__(256) void secondary_gen_kernel(TraceArgs a, const f
         if (!hit) {
             // No secondary rays from this pixel.  fs_main traces none; the record set still has a slot for them, which holds
             // what the trace kernels write for a ray that never enters the cube: all zeros.  The trace skips these slots.
-            for (uint32_t k = 0; k < n_secondary; k++) {
-                const uint64_t slot = (uint64_t)k * n_records + it.out;
+            for (uint32_t k = k_first; k < n_secondary; k++) {
+                const uint64_t slot = (uint64_t)(k - k_first) * n_records + it.out;
                 skip[slot] = 1u;
                 reinterpret_cast<uint4 *>(out)[slot] = make_uint4(0u, 0u, 0u, 0u);
             }
@@ -1334,7 +1336,7 @@ __global__ __launch_bounds__(256) void secondary_gen_kernel(TraceArgs a, const f
         float org[3], nrm[3];
         secondary_origin(pos, dir, rec.z & 0xFFu, rec.w, (rec.z & 0xFFu) != 0u ? aux_t[it.out] : 0.0f, org, nrm);
         const float n0 = nrm[0], n1 = nrm[1], n2 = nrm[2];
-        for (uint32_t k = 0; k < n_secondary; k++) {
+        for (uint32_t k = k_first; k < n_secondary; k++) {
             float d0, d1, d2;
             if (k == 0u) {
                 d0 = -s0; d1 = -s1; d2 = -s2;  // the shadow ray, shader.wgsl:276
@@ -1347,7 +1349,7 @@ __global__ __launch_bounds__(256) void secondary_gen_kernel(TraceArgs a, const f
                 const bool flip = (n0 * e0 + n1 * e1) + n2 * e2 < 0.0f;
                 d0 = flip ? -e0 : e0; d1 = flip ? -e1 : e1; d2 = flip ? -e2 : e2;
             }
-            const uint64_t slot = (uint64_t)k * n_records + it.out;
+            const uint64_t slot = (uint64_t)(k - k_first) * n_records + it.out;
             skip[slot] = 0u;
             float *dst = rays + 6ull * slot;
             dst[0] = org[0]; dst[1] = org[1]; dst[2] = org[2];
@@ -1393,12 +1395,12 @@ __global__ __launch_bounds__(256) void shade_kernel(TraceArgs a, const svo_hit *
     }
 }
 
-hipError_t launch_secondary_gen(const TraceArgs &args, const float *aux_t, float *rays, uint8_t *skip, svo_hit *out,
+hipError_t launch_secondary_gen(const TraceArgs &args, const float *aux_t, float *rays, uint8_t *skip, svo_hit *out, uint32_t k_first,
                                 uint32_t n_secondary, uint32_t n_records, hipStream_t stream) {
     (void)hipGetLastError();
     uint32_t blocks = (args.work.n_items + 255u) / 256u;
     if (blocks > 4096u) blocks = 4096u;
-    hipLaunchKernelGGL(secondary_gen_kernel, dim3(blocks), dim3(256), 0, stream, args, aux_t, rays, skip, out, n_secondary, n_records);
+    hipLaunchKernelGGL(secondary_gen_kernel, dim3(blocks), dim3(256), 0, stream, args, aux_t, rays, skip, out, k_first, n_secondary, n_records);
     return hipGetLastError();
 }
 

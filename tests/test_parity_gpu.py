@@ -559,11 +559,19 @@ def test_config3_rsvo_shell(pkg, gpu, O):
             assert_hits_equal(got, O.trace_frame(words, u, threads=8), f"rsvo shell depth {depth}")
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
-def test_secondary_rays_per_hit_pixel(pkg, gpu, O, monu9_words, small_words, variant):
+@pytest.fixture
+def fused_shadows(request, pkg, gpu):
+    gpu.set_option(pkg.gpu.OPT_FUSED_SHADOWS, request.param)
+    yield request.param
+    gpu.set_option(pkg.gpu.OPT_FUSED_SHADOWS, 2)  # the default (automatic)
+
+
+@pytest.mark.parametrize("variant,fused_shadows", [(0, 0), (1, 0), (1, 1)], indirect=["fused_shadows"])
+def test_secondary_rays_per_hit_pixel(pkg, gpu, O, monu9_words, small_words, variant, fused_shadows):
     """svo_render_secondary: ray 0 is fs_main's shadow ray (shader.wgsl:275-280), rays 1..3 share its origin;
     records are bit-exact against the oracle, the tile-sharded call equals the full frame, and ray 0 decides
-    exactly the pixels the shaded image shows in shadow."""
+    exactly the pixels the shaded image shows in shadow.  With fused shadow rays (STACK kernel) ray 0 is traced by
+    the lane that found the hit, inside the primary launch: its records must be the same."""
     gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
     for words, pose in ((monu9_words, ((0.1, 0.2, -1.5), (0.0, 0.0, 1.5))), (monu9_words, ((0.02, 0.31, 0.05), (0.3, -0.2, 1.0))),
                         (small_words, ((0.9, 0.8, -1.1), (-0.9, -0.8, 1.1)))):
