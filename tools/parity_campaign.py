@@ -20,10 +20,13 @@ def main():
     ap.add_argument("--h", type=int, default=360)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--count", action="store_true", help="adaptive mode: also compare the hit counters after each frame (slower: the oracle counts on one thread)")
+    ap.add_argument("--secondary", action="store_true", help="svo_render_secondary with 4 rays per hit pixel, random sun directions, ray 0 fused into the primary launch (SVO_OPT_FUSED_SHADOWS = 1): primary and secondary records against the oracle")
     a = ap.parse_args()
     pkg, O = entry.load_package(), entry.load_oracle()
     gpu = pkg.Gpu(0)
     gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+    if a.secondary:
+        gpu.set_option(pkg.gpu.OPT_FUSED_SHADOWS, 1)
     cam, look = pkg.scenes.terrain_camera(0, 16)
     z = np.load(os.path.join(ROOT, "tests", "golden", "monu9_vox.npz"))
     scenes = {
@@ -55,6 +58,12 @@ def main():
             flags = (0 if a.count else O.F_PAUSE_ADAPTIVE) | (O.F_MISC_BOOL if (k // 4) % 2 else 0)
             u = O.make_uniforms(pos=tuple(float(x) for x in pos), look=tuple(float(x) for x in lookv), fov=float(rng.choice([60, 90, 120])),
                                 width=a.w, height=a.h, flags=flags)
+            if a.secondary:
+                sun = rng.normal(size=3)
+                if k % 5 == 0:
+                    sun[rng.integers(0, 3)] = 0.0  # an axis-parallel component: octree_ray biases it
+                u.sun_dir[:3] = [float(x) for x in sun]
+                u.flags |= O.F_SHADOWS
             for f in ("camera", "camera_inverse", "dimensions", "sun_dir"):
                 getattr(render.uniforms, f)[:] = list(getattr(u, f))
             render.uniforms.flags, render.uniforms.misc_value = u.flags, u.misc_value
@@ -63,10 +72,25 @@ def main():
                 render.write_nodes(words)  # counters back to zero
             buf = render.alloc_hits(a.w * a.h)
             buf.fill_(-1)
-            got = pkg.render.hits_to_numpy(render.render(hits=buf)).view(np.uint32)
-            gpu.sync()
-            want = O.trace_frame(words, u, threads=threads).reshape(-1).view(np.uint32)
             total += 1
+            if a.secondary:
+                sbuf = render.alloc_hits(4 * a.w * a.h)
+                sbuf.fill_(-1)
+                render.render_secondary(4, hits=buf, secondary=sbuf)
+                gpu.sync()
+                oprim, osec = O.secondary_frame(words, u, 4, threads=threads)
+                got = pkg.render.hits_to_numpy(buf).view(np.uint32)
+                want = oprim.reshape(-1).view(np.uint32)
+                gsec = pkg.render.hits_to_numpy(sbuf).view(np.uint32).reshape(4, -1, 4)
+                wsec = osec.reshape(4, -1).view(np.uint32).reshape(4, -1, 4)
+                if not np.array_equal(gsec, wsec):
+                    bad += 1
+                    per_set = [int((gsec[j] != wsec[j]).any(axis=1).sum()) for j in range(4)]
+                    print(f"SECONDARY MISMATCH scene {name} pose {k} pos {pos.tolist()} look {lookv.tolist()} sun {list(u.sun_dir)[:3]} flags {u.flags}: differing records per set {per_set}", flush=True)
+            else:
+                got = pkg.render.hits_to_numpy(render.render(hits=buf)).view(np.uint32)
+                gpu.sync()
+                want = O.trace_frame(words, u, threads=threads).reshape(-1).view(np.uint32)
             if a.count and not np.array_equal(render.read_nodes(words.size), O.count_frame(words, u)):
                 bad += 1
                 print(f"COUNTER MISMATCH scene {name} pose {k} pos {pos.tolist()} look {lookv.tolist()} flags {flags}", flush=True)
