@@ -74,18 +74,19 @@ def main():
             buf.fill_(-1)
             total += 1
             if a.secondary:
-                sbuf = render.alloc_hits(4 * a.w * a.h)
+                ns = 1 if a.count else 4  # with live counters: fs_main's own ray set (primary + shadow), which count_frame models
+                sbuf = render.alloc_hits(ns * a.w * a.h)
                 sbuf.fill_(-1)
-                render.render_secondary(4, hits=buf, secondary=sbuf)
+                render.render_secondary(ns, hits=buf, secondary=sbuf)
                 gpu.sync()
-                oprim, osec = O.secondary_frame(words, u, 4, threads=threads)
+                oprim, osec = O.secondary_frame(words, u, ns, threads=threads)
                 got = pkg.render.hits_to_numpy(buf).view(np.uint32)
                 want = oprim.reshape(-1).view(np.uint32)
-                gsec = pkg.render.hits_to_numpy(sbuf).view(np.uint32).reshape(4, -1, 4)
-                wsec = osec.reshape(4, -1).view(np.uint32).reshape(4, -1, 4)
+                gsec = pkg.render.hits_to_numpy(sbuf).view(np.uint32).reshape(ns, -1, 4)
+                wsec = osec.reshape(ns, -1).view(np.uint32).reshape(ns, -1, 4)
                 if not np.array_equal(gsec, wsec):
                     bad += 1
-                    per_set = [int((gsec[j] != wsec[j]).any(axis=1).sum()) for j in range(4)]
+                    per_set = [int((gsec[j] != wsec[j]).any(axis=1).sum()) for j in range(ns)]
                     print(f"SECONDARY MISMATCH scene {name} pose {k} pos {pos.tolist()} look {lookv.tolist()} sun {list(u.sun_dir)[:3]} flags {u.flags}: differing records per set {per_set}", flush=True)
             else:
                 got = pkg.render.hits_to_numpy(render.render(hits=buf)).view(np.uint32)
