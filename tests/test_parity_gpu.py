@@ -738,8 +738,11 @@ def test_bench_workload_full_size(pkg, gpu, O):
     assert np.array_equal(frame.reshape(-1).view(np.uint32), want.reshape(-1).view(np.uint32))
 
 
-def test_shaded_tiles_match_full_frame(pkg, gpu, O, monu9_words):
-    """svo_render_tiles with rgba_out: the sharded, shaded image equals the unsharded one pixel for pixel."""
+@pytest.mark.parametrize("fused_shadows", [0, 1], indirect=True)
+def test_shaded_tiles_match_full_frame(pkg, gpu, O, monu9_words, fused_shadows):
+    """svo_render_tiles with rgba_out: the sharded, shaded image equals the unsharded one pixel for pixel (shadow rays as a
+    second launch and fused into the primary one)."""
+    gpu.set_option(pkg.gpu.OPT_VARIANT, pkg.gpu.VARIANT_STACK)
     W, H, tw, th, ranks = 192, 96, 64, 8, 3
     u = O.make_uniforms(width=W, height=H, flags=O.F_PAUSE_ADAPTIVE | O.F_SHADOWS)
     render = pkg.Render(gpu, (W, H), monu9_words, capacity=monu9_words.size)
