@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--count", action="store_true", help="adaptive mode: also compare the hit counters after each frame (slower: the oracle counts on one thread)")
     ap.add_argument("--secondary", action="store_true", help="svo_render_secondary with 4 rays per hit pixel, random sun directions, ray 0 fused into the primary launch (SVO_OPT_FUSED_SHADOWS = 1): primary and secondary records against the oracle")
+    ap.add_argument("--deep", action="store_true", help="deep trees instead (depth-20 fractal, depth-19 terrain): the 19-level stack instantiations, SVO_OPT_TREE_DEPTH = 20")
     a = ap.parse_args()
     pkg, O = entry.load_package(), entry.load_oracle()
     gpu = pkg.Gpu(0)
@@ -35,6 +36,14 @@ def main():
         "random9": pkg.scenes.random_tree(seed=5, max_depth=9, p_split=0.55, p_solid=0.25, max_words=1 << 21),
         "fractal14": pkg.scenes.fractal(seed=1, max_depth=14, cam=(-0.9, -0.9, -0.9), lod_c=200.0, min_depth=4, max_words=8_000_000),
     }
+    if a.deep:
+        gpu.set_option(pkg.gpu.OPT_TREE_DEPTH, 20)
+        scenes = {
+            "fractal20": pkg.scenes.fractal(seed=1, max_depth=20, cam=(-0.9999, -0.9999, -0.9999), lod_c=1200.0, min_depth=4, max_words=30_000_000),
+            "terrain19": pkg.scenes.terrain(seed=2, max_depth=19, cam=pkg.scenes.terrain_camera(2, 19)[0], lod_c=250.0, max_words=30_000_000),
+        }
+        for name, words in scenes.items():
+            print(f"{name}: {words.size} words, depth {pkg.scenes.max_depth(words)}", flush=True)
     rng = np.random.default_rng(a.seed)
     threads = os.cpu_count() or 8
     total = bad = 0
@@ -52,6 +61,10 @@ def main():
             else:            # near a face of the cube
                 pos = rng.uniform(-0.99, 0.99, 3); pos[rng.integers(0, 3)] = rng.choice([-1.0, 1.0]) * rng.uniform(0.98, 1.02)
             target = rng.uniform(-0.8, 0.8, 3) if kind != 1 else rng.uniform(-0.3, 0.3, 3)
+            if a.deep and k % 2 == 0:  # next to the finest geometry (the generators refine towards their LOD camera)
+                base = np.array([-0.999, -0.9985, -0.998]) if name.startswith("fractal") else np.array(pkg.scenes.terrain_camera(2, 19)[0])
+                pos = base + rng.normal(size=3) * 10.0 ** rng.uniform(-4.0, -1.5)
+                target = base + rng.normal(size=3) * 0.01 - np.array([0.0, 0.02, 0.0])
             lookv = target - pos
             if np.linalg.norm(lookv) < 1e-3 or abs(lookv[0]) + abs(lookv[2]) < 1e-4:
                 lookv = np.array([0.3, -0.2, 0.9])
