@@ -3,18 +3,23 @@
 
 One "step" = one frame: every primary ray of the workload traced once by the HIP kernel
 (svo_render / svo_render_tiles through the C ABI), node array resident in HBM, hit records left in
-HBM.  With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the frame's tiles are
-dealt round-robin to ranks and each step ends with ONE RCCL gather of hit records to rank 0 plus
-the un-permute on rank 0 (strong scaling: the frame is fixed).
+HBM.  With --gpus N > 1 (one rank per GPU; started by torch.distributed.run, or by this script itself
+as a child process when it is called as plain `python bench.py --gpus N`) the frame's tiles are dealt
+round-robin to ranks and each step ends with ONE RCCL gather of hit records to rank 0 (svo_gather_frame,
+behind the C ABI) plus the un-permute on rank 0 (strong scaling: the frame is fixed).
 
 Workload (BASELINE.json metric "Mrays/sec at 1920x1080, depth-16 SVO"): deterministic LOD terrain,
 max depth 16, ~107 M words (428 MB, larger than the 256 MiB Infinity Cache, under the 2^27-word
 layout cap), camera standing on the terrain, 1920x1080 primary rays, static tree
 (pause_adaptive), no shadows.  Data is synthetic (seeded generator, no reference counterpart).
+Beside the headline the line carries, measured in the same run outside the timed region: the first frame
+of a layout (no strip schedule yet), a moving camera, and the 4K frame of the same scene (config.also).
 """
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
@@ -25,6 +30,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# vector-instruction issue peak: 256 CUs x 4 SIMDs, one wave64 instruction per 2 cycles (SIMD-32), 2.4 GHz
+VALU_PEAK_GINSTR_S = 256 * 4 * 2.4 / 2.0
 
 WORKLOADS = {
     # name: (width, height, scene kwargs)
@@ -32,9 +39,28 @@ WORKLOADS = {
     "terrain16_4k": dict(width=3840, height=2160, seed=0, max_depth=16, lod_c=1500.0, max_words=125_000_000),
 }
 # Mean algorithmic bytes per ray, B_ray = 4 * W_ray + 16, W_ray counted exactly by the
-# oracle over the FULL frame of the workload (tools/ray_stats.py; stated in DESIGN.md).  bench.py
-# re-measures it on the cpu_baseline sample and reports both.
+# oracle over the FULL frame of the workload (stated in DESIGN.md).  bench.py re-measures it on the
+# cpu_baseline sample and reports both.
 ALGO_BYTES_PER_RAY = {"terrain16_1080p": 243.0228, "terrain16_4k": None}
+
+
+def free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (torch.distributed.run) before
+    anything here has touched the GPU, relay what it prints and exit with its code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, env=env)
+    sys.exit(proc.returncode)
 
 
 def main():
@@ -46,9 +72,13 @@ def main():
     ap.add_argument("--tile-w", type=int, default=64)
     ap.add_argument("--tile-h", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cold-frame / moving-camera / other-workload measurements")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: validation mode for boxes with fewer GPUs than ranks -- ranks share the visible GPUs and "
                          "the gather is staged through host memory (not a performance configuration)")
+    ap.add_argument("--gather", default="abi", choices=["abi", "torch"],
+                    help="N>1, backend nccl: the frame-end gather goes through the C ABI (svo_gather_frame: the library's own RCCL "
+                         "communicator, one per lane) or through torch.distributed.gather")
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
                     help="consecutive frames rotate over this many HIP streams / device contexts, so the serial tail of one "
                          "frame's rays overlaps the next frames.  0 = default: 1 at N=1 (frames serial, which is what "
@@ -62,6 +92,8 @@ def main():
                          "process group on a single GPU")
     ap.add_argument("--cpu-frac", type=int, default=1, help="cpu_baseline traces the top 1/n of the frame's rows")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     if a.frames_in_flight > 3:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: one hardware queue per lane
 
@@ -70,12 +102,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        a.gpus = world
+    a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if a.backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} with backend nccl needs {world} GPUs, {torch.cuda.device_count()} visible "
+                         "(--backend gloo shares the visible ones: validation only)")
     if a.backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -83,10 +115,7 @@ def main():
     if pipelined:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:  # only the single-process validation mode gets here without a launcher
-            import socket
-            with socket.socket() as sock:
-                sock.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+            os.environ["MASTER_PORT"] = str(free_port())
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -100,7 +129,6 @@ def main():
         dist.barrier()
     pkg = entry.load_package()
     wl = WORKLOADS[a.workload]
-    W, H = wl["width"], wl["height"]
     cam, look = pkg.scenes.terrain_camera(wl["seed"], wl["max_depth"])
     t0 = time.time()
     words = pkg.scenes.terrain(seed=wl["seed"], max_depth=wl["max_depth"], cam=cam, lod_c=wl["lod_c"],
@@ -108,13 +136,9 @@ def main():
     gen_s = time.time() - t0
 
     gpu = pkg.Gpu(local_rank)
-    render = pkg.Render(gpu, (W, H), words, capacity=words.size)
+    render = pkg.Render(gpu, (wl["width"], wl["height"]), words, capacity=words.size)
     render.set_flags(pause_adaptive=True, shadows=False)
-    render.update(pkg.Settings(fov=90.0), pkg.Character(cam, look))
-    gpu.set_option(pkg.gpu.OPT_TIMING, max(a.steps, 1))
-
     tw, th = a.tile_w, a.tile_h
-    n_rays = W * H
     if a.frames_in_flight == 0:
         a.frames_in_flight = 1 if (not pipelined or a.backend == "gloo") else 3
     # lane 0 = the context above on torch's current stream; further lanes: own HIP stream + context, same node buffer
@@ -122,33 +146,59 @@ def main():
     for _ in range(a.frames_in_flight - 1):
         s_k = torch.cuda.Stream()
         gpu_k = pkg.Gpu(local_rank, stream=s_k.cuda_stream)
-        render_k = pkg.Render.share_nodes(gpu_k, render)
-        gpu_k.set_option(pkg.gpu.OPT_TIMING, max(a.steps, 1))
-        lanes.append((gpu_k, render_k, s_k))
-    if not pipelined and len(lanes) > 1:
-        bufs = [r.alloc_hits(n_rays) for _, r, _ in lanes]
-        counter = [0]
+        lanes.append((gpu_k, pkg.Render.share_nodes(gpu_k, render), s_k))
+    gather_mode = None
+    if pipelined and a.backend == "nccl":
+        gather_mode = a.gather
+        if gather_mode == "abi":
+            # one RCCL communicator per lane behind the C ABI; rank 0's ids travel over the launcher's process group
+            try:
+                for g, _, _ in lanes:
+                    ids = [pkg.Gpu.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    g.comm_init_rank(ids[0], world, rank)
+            except pkg.SvoError as e:  # (a rank-local failure: the other ranks would hang in the collective, so say it loudly)
+                raise SystemExit(f"rank {rank}: RCCL communicator behind the C ABI failed: {e}; rerun with --gather torch")
 
-        def step():
-            k = counter[0] % len(lanes)
-            counter[0] += 1
-            lanes[k][1].render(hits=bufs[k])
-            return bufs[k]
-    elif not pipelined:
-        hits = render.alloc_hits(n_rays)
+    def barrier():
+        torch.cuda.synchronize()
+        if pipelined:
+            dist.barrier()
+            torch.cuda.synchronize()
 
-        def step():
-            render.render(hits=hits)
-            return hits
-    else:
+    def frame_loop(W, H):
+        """(step, drain) for W x H frames of the scene on the lanes above"""
+        for _, r, _ in lanes:
+            r.resize((W, H))
+            r.update(pkg.Settings(fov=90.0), pkg.Character(cam, look))
+        n_rays = W * H
+        if not pipelined and len(lanes) > 1:
+            bufs = [r.alloc_hits(n_rays) for _, r, _ in lanes]
+            counter = [0]
+
+            def step():
+                k = counter[0] % len(lanes)
+                counter[0] += 1
+                lanes[k][1].render(hits=bufs[k])
+                return bufs[k]
+            return step, None
+        if not pipelined:
+            hits = render.alloc_hits(n_rays)
+
+            def step():
+                render.render(hits=hits)
+                return hits
+            return step, None
         assert W % tw == 0 and H % th == 0
         # frame i's RCCL gather overlaps frame i+1's trace (double-buffered); rank 0 un-permutes each frame
         if a.backend == "nccl":
             traces = [(lambda buf, r=r: r.render_tiles(tw, th, rank, world, hits=buf)) for _, r, _ in lanes]
             assemble = [(lambda g, out, r=r: r.assemble_tiles(g, tw, th, out=out)) for _, r, _ in lanes]
             pack = [(lambda rec, wire, r=r: r.pack_records(rec, wire)) for _, r, _ in lanes] if a.wire == "packed12" else None
+            gather = [((lambda send, recv, g=g: g.gather_frame(send, recv, 0)), g.gather_wait) for g, _, _ in lanes] \
+                if gather_mode == "abi" else None
             pipe = pkg.sharding.FramePipeline(traces, W, H, tw, th, rank, world, f"cuda:{local_rank}",
-                                              streams=[s for _, _, s in lanes], assemble=assemble, pack=pack)
+                                              streams=[s for _, _, s in lanes], assemble=assemble, pack=pack, gather=gather)
         else:
             n_pad_v = pkg.sharding.padded_tile_count(W, H, tw, th, world)
 
@@ -162,37 +212,83 @@ def main():
 
             pipe = pkg.sharding.FramePipeline([via_host(r) for _, r, _ in lanes], W, H, tw, th, rank, world, "cpu",
                                               streams=[s for _, _, s in lanes], pack=True if a.wire == "packed12" else None)
-        step = pipe.step
+        return pipe.step, pipe.drain
 
-    def barrier():
-        torch.cuda.synchronize()
+    def measure(W, H, steps, warmup):
+        """K timed frames: (elapsed s [max over ranks], kernel ms of the K launches, last frame)"""
+        step, drain = frame_loop(W, H)
+        for g, _, _ in lanes:
+            g.set_option(pkg.gpu.OPT_TIMING, max(steps, 1))
+        for _ in range(warmup):
+            step()
+        if drain:
+            drain()
+        barrier()
+        for g, _, _ in lanes:
+            g.timing_collect()  # drop the warm-up launches' records
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        if drain:
+            out = drain()  # every one of the K frames is gathered and assembled inside the timed region
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        # per-launch kernel durations of exactly the K timed launches: HIP event pairs recorded by the C ABI
+        # around each launch on the launch stream
+        kms = np.concatenate([g.timing_collect() for g, _, _ in lanes])
+        assert len(kms) == steps
         if pipelined:
-            dist.barrier()
-            torch.cuda.synchronize()
+            t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if a.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, kms, out
 
-    for _ in range(a.warmup):
-        step()
-    if pipelined:
-        pipe.drain()
-    barrier()
-    for g, _, _ in lanes:
-        g.timing_collect()  # drop the warm-up launches' records
-    t_start = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    if pipelined:
-        out = pipe.drain()  # every one of the K frames is gathered and assembled inside the timed region
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    # per-launch kernel durations of exactly the K timed launches: HIP event pairs recorded by the C ABI
-    # around each launch on the launch stream
-    kms = np.concatenate([g.timing_collect() for g, _, _ in lanes])
-    assert len(kms) == a.steps
-    if pipelined:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if a.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    W, H = wl["width"], wl["height"]
+    n_rays = W * H
+    elapsed, kms, out = measure(W, H, a.steps, a.warmup)
     gpu.sync()
+    frame = out.reshape(-1, 4).cpu().numpy().view(np.uint32) if rank == 0 else None
+
+    # ---- beside the headline, same run, outside its timed region ----
+    extras = {}
+    if not a.no_extras:
+        k_extra = max(10, min(a.steps, 50))
+        if not pipelined:
+            # (1) the first frame of a layout: no strip schedule yet (screen order); the schedule is dropped before every sample
+            hits = render.alloc_hits(n_rays)
+            cold = []
+            for _ in range(7):
+                gpu.set_option(pkg.gpu.OPT_SCHEDULE, 2)  # (setting the period forgets the schedule)
+                render.render(hits=hits)
+                cold.append(gpu.last_render_ms())
+            extras["cold_frame_ms"] = round(float(np.median(cold)), 4)
+            # (2) a moving camera: 1 degree of yaw per frame, schedule rebuilt every 2nd frame (the default period)
+            gpu.timing_collect()
+            lx, ly, lz = look
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(k_extra):
+                ang = math.radians(1.0) * (i + 1)
+                render.update(pkg.Settings(fov=90.0), pkg.Character(cam, (lx * math.cos(ang) + lz * math.sin(ang), ly,
+                                                                          -lx * math.sin(ang) + lz * math.cos(ang))))
+                render.render(hits=hits)
+            torch.cuda.synchronize()
+            extras["motion_ms"] = round((time.perf_counter() - t0) / k_extra * 1e3, 4)
+            extras["motion_kernel_ms"] = round(float(np.mean(gpu.timing_collect())), 4)
+            extras["motion"] = "1 degree of yaw per frame, strip schedule rebuilt every 2nd frame; wall time per frame incl. the schedule kernels"
+            render.update(pkg.Settings(fov=90.0), pkg.Character(cam, look))
+        # (3) the other frame size of the same scene and pose (the 4K frame is the one the 1 -> 8 GPU target refers to)
+        other = "terrain16_4k" if a.workload == "terrain16_1080p" else "terrain16_1080p"
+        ow = WORKLOADS[other]
+        e2, k2, _ = measure(ow["width"], ow["height"], k_extra, 3)
+        extras["also"] = {"workload": other, "value": round(ow["width"] * ow["height"] * k_extra / e2 / 1e6, 2), "unit": "Mrays/s",
+                          "steps": k_extra, "ms_per_step": round(e2 / k_extra * 1e3, 4), "kernel_avg_ms": round(float(np.mean(k2)), 4)}
+        if ALGO_BYTES_PER_RAY.get(other) and not pipelined:
+            extras["also"]["roofline_frac"] = round(ALGO_BYTES_PER_RAY[other] * ow["width"] * ow["height"] / (float(np.mean(k2)) * 1e-3) / 1e9
+                                                    / HBM_PEAK_GBS, 5)
+        for _, r, _ in lanes:
+            r.resize((W, H))
+            r.update(pkg.Settings(fov=90.0), pkg.Character(cam, look))
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
@@ -200,7 +296,12 @@ def main():
         kernel_avg_ms = float(np.mean(kms))
         # rays this rank's launch traced (rank 0 owns the most tiles)
         rays_per_launch = n_rays if not pipelined else pkg.sharding.local_tile_count(W, H, tw, th, 0, world) * tw * th
-        frame = out.reshape(-1, 4).cpu().numpy().view(np.uint32)
+        if not pipelined:
+            sharding = "none"
+        else:
+            via = {"abi": "svo_gather_frame (RCCL behind the C ABI)", "torch": "torch.distributed.gather (RCCL)", None: "gloo via host memory"}[gather_mode]
+            sharding = (f"tiles {tw}x{th} round-robin, 1 gather per frame through {via}, {12 if a.wire == 'packed12' else 16} B/ray, "
+                        "overlapped with the following frames' traces")
         result = {
             "metric": "Mrays/sec at 1920x1080, depth-16 SVO; achieved HBM GB/s vs peak",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -208,8 +309,13 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
             "config": {"workload": a.workload, "width": W, "height": H, "octree_max_depth": wl["max_depth"],
                        "node_words": int(words.size), "node_bytes": int(words.size) * 4, "rays_per_step": n_rays,
-                       "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight, "backend": a.backend if pipelined else None, "sharding": "none" if not pipelined else f"tiles {tw}x{th} round-robin, 1 RCCL gather per frame ({12 if a.wire == 'packed12' else 16} B/ray) overlapped with the following frames' traces",
-                       "scene_gen_s": round(gen_s, 1)},
+                       "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight,
+                       "step_semantics": ("frames are serial: ms_per_step is one frame's latency and roofline.kernel_avg_ms one un-overlapped launch"
+                                          if a.frames_in_flight == 1 else
+                                          f"{a.frames_in_flight} frames in flight on separate HIP streams: ms_per_step is the interval between completed "
+                                          "frames (throughput), not a frame's latency, and kernel durations are of overlapping launches"),
+                       "backend": a.backend if pipelined else None, "gather": gather_mode, "sharding": sharding,
+                       "scene_gen_s": round(gen_s, 1), **extras},
         }
         cpu = None
         bytes_per_ray = ALGO_BYTES_PER_RAY.get(a.workload)
@@ -219,8 +325,8 @@ def main():
             for f in ("camera", "camera_inverse", "dimensions", "sun_dir"):
                 getattr(u, f)[:] = list(getattr(render.uniforms, f))
             u.flags, u.misc_value = render.uniforms.flags, render.uniforms.misc_value
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            cores = max(1, min(cores, 64))
+            host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = max(1, min(host_cores, 64))  # the oracle's thread pool is capped at 64
             # bounded sample: the top H / cpu_frac rows... a full frame is only seconds of CPU work, so by
             # default (cpu_frac = 1) the sample is the whole frame and the byte count below is exact
             rows = H // a.cpu_frac
@@ -235,28 +341,45 @@ def main():
             # parity of the frame the GPU just produced, on the sampled rows (checker, not the product)
             got = frame.reshape(H, W, 4)[:rows].reshape(-1, 4)
             parity = bool(np.array_equal(got, rec.view(np.uint32).reshape(-1, 4)))
-            cpu = {"value": round(len(rec) / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            cpu = {"value": round(len(rec) / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores,
+                   "host_cores_available": host_cores, "host_cores_total": os.cpu_count(), "kind": "port",
                    "sample": f"rows 0..{rows - 1} of the same frame ({len(rec)} rays, {cpu_s:.1f} s), "
                              f"oracle/svo_oracle.c (restart-from-root algorithm of shader.wgsl), {cores} pthreads",
                    "sample_algo_bytes_per_ray": round(sample_bpr, 3), "w_restart_words_per_ray": round(float(st[:, 0].mean()), 2),
                    "gpu_frame_matches_oracle_on_sample": parity}
         if bytes_per_ray is not None:
             achieved = bytes_per_ray * rays_per_launch / (kernel_avg_ms * 1e-3) / 1e9
-            traffic = None
+            traffic = valu = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if tj.get("workload") == a.workload and world == 1:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    valu = tj.get("valu_wave_instructions_per_launch")
+            # `bound` names the contractual ceiling (BASELINE.json: fraction of the HBM-read roofline on ALGORITHMIC bytes); the
+            # measured limiter is vector-instruction issue plus dependent-load latency: memory-side traffic is a fraction of
+            # the algorithmic bytes (L2 absorbs the shared ancestors), see roofline_valu and DESIGN.md 6
             result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                                  "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (not this run)",
+                                  "achieved_algorithmic_gbs": round(achieved, 2),
+                                  "measured_hbm_gbs": round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 2) if traffic else None,
+                                  "measured_limiter": "vector-instruction issue + dependent-load latency (not HBM bandwidth)",
                                   "kernel": "trace_stack_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4),
                                   "algo_bytes_per_ray": round(bytes_per_ray, 3), "rays_per_launch": rays_per_launch}
+            if valu:
+                ach = valu / (kernel_avg_ms * 1e-3) / 1e9
+                result["roofline_valu"] = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s",
+                                           "frac": round(ach / VALU_PEAK_GINSTR_S, 4), "instructions_per_launch": valu,
+                                           "source": "profiles/traffic.json: SQ_INSTS_VALU of this workload's launch (rocprofv3 --pmc pass, not this run); "
+                                                     "peak = 1024 SIMDs x 1 wave64 instruction / 2 cycles x 2.4 GHz"}
         if cpu is not None:
             result["cpu_baseline"] = cpu
         print(json.dumps(result), flush=True)
     if pipelined:
         dist.barrier()
+        for g, _, _ in lanes:
+            g.close()  # (communicators go before the process group)
         dist.destroy_process_group()
 
 

@@ -24,6 +24,11 @@
  *   svo_scan_read                 map_async + device.poll(Wait) + counter reset
  *                                 (adaptive.rs:12-23, :76-87)
  *   svo_sync                      device.poll(Maintain::Wait)
+ *   svo_comm_* / svo_gather_frame no reference counterpart (the reference drives one device, main.rs:40-88): the
+ *                                 frame-end exchange of the tile-sharded multi-GPU frame, RCCL behind the boundary
+ *                                 (SURVEY.md 8b "Threading", 8e): communicator set-up for one process per GPU
+ *                                 (svo_comm_init_rank) or one process driving all GPUs (svo_comm_init_all), and the
+ *                                 ONE gather of hit records to rank 0 per frame
  * Errors: the reference unwraps/panics (gpu.rs:24,39; adaptive.rs:66,124); here every call
  * returns 0 on success or a negative svo_status, and svo_last_error() gives the text.
  * Threading: like the reference (all device calls from one thread, main.rs:40-88) a ctx is not
@@ -46,7 +51,8 @@ typedef enum svo_status {
     SVO_ERR_ARG = -1,     /* bad argument */
     SVO_ERR_HIP = -2,     /* a HIP runtime call failed; see svo_last_error */
     SVO_ERR_STATE = -3,   /* call order (e.g. render before nodes_alloc) */
-    SVO_ERR_NO_DEVICE = -4
+    SVO_ERR_NO_DEVICE = -4,
+    SVO_ERR_COMM = -5     /* RCCL missing or a collective call failed; see svo_last_error */
 } svo_status;
 
 /* Uniform flags: the reference's five 1-byte bools (render.rs:294-299) as explicit bits. */
@@ -97,13 +103,18 @@ typedef enum svo_option {
     SVO_OPT_TREE_DEPTH = 9,  /* upper bound of the octree depth (Settings.octree_depth, app.rs:24); default 16.
                                 <= 16: default kernel; <= 23: deep-stack kernel; above: the general RESTART kernel */
     SVO_OPT_BLOCK_SHAPE = 10, /* log2 of the width of the 64-pixel blocks a wave works on (3: 8x8, 4: 16x4, ...) */
-    SVO_OPT_DEBUG_BUFFER = 7, /* device pointer receiving 8 words per wave: start, queue-dry, end (10 ns ticks), rounds, ... */
+    SVO_OPT_DEBUG_BUFFER = 7, /* device pointer receiving 16 words per wave: start, queue-dry, end (10 ns ticks), rounds, ...,
+                                 shader cycles per phase (refill, descent, step), descent-loop shape (tools/wave_timeline.py) */
     SVO_OPT_SCAN_CLEARS_COUNTERS = 11, /* 1: svo_scan_dispatch also zeroes the hit counters it has scanned, so that the
                                           host need not re-upload the whole array to reset them (svo_nodes_scatter) */
     SVO_OPT_FUSED_SHADOWS = 12, /* shaded frames with shadows (svo_render* with rgba_out), STACK variant: 1 = the lane that finds a hit goes
                                    on with that pixel's shadow ray inside the primary launch; 0 = shadow rays are a second launch;
                                    2 (default) = fused for trees deeper than 16 levels (SVO_OPT_TREE_DEPTH) and frames of 4 Mpixel
                                    and more, where it measured faster.  The image is the same either way. */
+    SVO_OPT_PAIR_TABLE = 13, /* STACK variant, static trees (pause_adaptive): descend two levels per dependent load through a
+                                device-built table that stores, for every node word, the 8 words of its children (8 x the node
+                                buffer in HBM, built on the first trace after the words changed).  1 (default) on, 0 off.
+                                Results do not depend on it. */
     SVO_OPT_PRIO_STEPS = 6   /* accepted and ignored: raising the issue priority of waves with old rays measured no effect and
                                 left the kernel */
 } svo_option;
@@ -118,8 +129,19 @@ const char *svo_last_error(const svo_ctx *ctx);
 int svo_sync(svo_ctx *ctx);
 
 int svo_nodes_alloc(svo_ctx *ctx, size_t capacity_words);
-/* Use caller-owned device memory as the node buffer instead (no copy). */
+/* Use caller-owned device memory as the node buffer instead (no copy).  The library cannot see writes the caller makes to
+ * that memory: call svo_nodes_invalidate after each of them, or the STACK kernel descends from a stale top table. */
 int svo_nodes_bind_device(svo_ctx *ctx, uint32_t *device_words, size_t capacity_words);
+/* Trace from the SAME node buffer as `owner` (same device; frames in flight on several contexts / streams, one buffer).
+ * The contexts share the words, a generation counter and the stream ordering of writes: after svo_nodes_write /
+ * svo_nodes_scatter / svo_nodes_invalidate through ANY of them, every one rebuilds its top table and strip schedule
+ * before its next trace, and that trace waits (on the device) for the write.  A write does not wait for traces other
+ * contexts still have in flight: that ordering stays with the caller (svo_sync them first), as with any shared buffer.
+ * The buffer lives until the last context bound to it lets go. */
+int svo_nodes_share(svo_ctx *ctx, svo_ctx *owner);
+/* The words of the node buffer were changed behind the library's back (a kernel or copy of the caller's, enqueued on
+ * this context's stream before this call): bump the generation, like a write. */
+int svo_nodes_invalidate(svo_ctx *ctx);
 int svo_nodes_write(svo_ctx *ctx, size_t word_offset, const uint32_t *host_words, size_t n);
 /* Incremental form of the reference's per-frame `queue.write_buffer(&node_buffer, 0, nodes)` (app.rs:113-118): write
  * host_words[i] to word indices[i] (host pointers, n pairs, indices unique), e.g. the words the streaming loop changed
@@ -172,6 +194,31 @@ int svo_assemble_tiles(svo_ctx *ctx, const svo_hit *gathered, uint32_t world, ui
 int svo_pack_records(svo_ctx *ctx, const svo_hit *records, size_t n, uint32_t *wire_out);
 int svo_assemble_tiles_packed(svo_ctx *ctx, const uint32_t *gathered_wire, uint32_t world, uint32_t n_pad, uint32_t width,
                               uint32_t height, uint32_t tile_w, uint32_t tile_h, svo_hit *frame_out);
+/* ---- multi-GPU frame end: one gather of hit records to the root rank per frame, RCCL over xGMI.  librccl is
+ * loaded on first use (dlopen); without it these return SVO_ERR_COMM and everything else keeps working. ----
+ * One process per GPU: rank 0 makes an id (svo_comm_unique_id), hands its 128 bytes to the other ranks by any means (the
+ * launcher's rendezvous, a file, MPI, torch.distributed), and every rank calls svo_comm_init_rank on its context:
+ * collective, blocks until all `world` ranks have called it. */
+#define SVO_COMM_ID_BYTES 128
+int svo_comm_unique_id(uint8_t id_out[SVO_COMM_ID_BYTES]);
+int svo_comm_init_rank(svo_ctx *ctx, const uint8_t id[SVO_COMM_ID_BYTES], int world, int rank);
+/* One process (one thread) driving n contexts on n different devices, the reference's threading model (main.rs:40-88):
+ * ncclCommInitAll; ctxs[r] becomes rank r. */
+int svo_comm_init_all(int n, svo_ctx *const *ctxs);
+int svo_comm_destroy(svo_ctx *ctx);
+/* This rank's contribution to the frame-end gather: `bytes` bytes (a multiple of 4, the same on every rank) from `send` to
+ * `recv_on_root` + rank * bytes on rank `root` (device pointers; recv_on_root is ignored elsewhere and may be NULL).  Every
+ * rank of the communicator must call it once per frame, in the same order of frames.  Asynchronous: the exchange runs on a
+ * communication stream of the context, ordered BEHIND everything enqueued on the ctx stream so far (the trace / pack that
+ * produced `send`), so the ctx stream is free to start the next frame while records travel.  svo_gather_wait makes the ctx
+ * stream wait for the gathers issued so far: call it before work on the ctx stream reads recv_on_root (svo_assemble_tiles on
+ * the root) or overwrites `send`; svo_sync waits for both streams. */
+int svo_gather_frame(svo_ctx *ctx, const void *send, size_t bytes, void *recv_on_root, int root);
+int svo_gather_wait(svo_ctx *ctx);
+/* The same for the single-process form, all ranks in one call: send[r] is rank r's buffer (on ctxs[r]'s device);
+ * recv_on_root lives on ctxs[root]'s device. */
+int svo_gather_frame_all(int n, svo_ctx *const *ctxs, const void *const *send, size_t bytes, void *recv_on_root, int root);
+
 /* octree_ray over n explicit rays (6 floats each: pos.xyz, dir.xyz; device pointers). */
 int svo_trace_rays(svo_ctx *ctx, const float *rays, size_t n_rays, svo_hit *hits_out);
 

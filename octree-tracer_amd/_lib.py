@@ -39,7 +39,8 @@ class TerrainParams(C.Structure):
 
 DEVICE_SYMBOLS = [
     "svo_ctx_create", "svo_ctx_destroy", "svo_ctx_set_stream", "svo_set_option", "svo_last_error", "svo_sync",
-    "svo_nodes_alloc", "svo_nodes_bind_device", "svo_nodes_write", "svo_nodes_scatter", "svo_nodes_read", "svo_nodes_device_ptr",
+    "svo_nodes_alloc", "svo_nodes_bind_device", "svo_nodes_write", "svo_nodes_scatter", "svo_nodes_read", "svo_nodes_device_ptr", "svo_nodes_share", "svo_nodes_invalidate",
+    "svo_comm_unique_id", "svo_comm_init_rank", "svo_comm_init_all", "svo_comm_destroy", "svo_gather_frame", "svo_gather_frame_all", "svo_gather_wait",
     "svo_set_uniforms", "svo_render", "svo_render_host", "svo_render_tiles", "svo_render_secondary", "svo_render_tiles_secondary", "svo_assemble_tiles", "svo_assemble_tiles_packed", "svo_pack_records", "svo_trace_rays",
     "svo_last_render_ms", "svo_timing_collect", "svo_diag_gather", "svo_scan_dispatch", "svo_scan_read",
 ]
@@ -93,6 +94,15 @@ def lib():
     sig("svo_nodes_scatter", C.c_int, vp, vp, vp, sz)
     sig("svo_nodes_read", C.c_int, vp, sz, vp, sz)
     sig("svo_nodes_device_ptr", C.c_int, vp, C.POINTER(vp), C.POINTER(sz))
+    sig("svo_nodes_share", C.c_int, vp, vp)
+    sig("svo_nodes_invalidate", C.c_int, vp)
+    sig("svo_comm_unique_id", C.c_int, vp)
+    sig("svo_comm_init_rank", C.c_int, vp, vp, C.c_int, C.c_int)
+    sig("svo_comm_init_all", C.c_int, C.c_int, C.POINTER(vp))
+    sig("svo_comm_destroy", C.c_int, vp)
+    sig("svo_gather_frame", C.c_int, vp, vp, sz, vp, C.c_int)
+    sig("svo_gather_wait", C.c_int, vp)
+    sig("svo_gather_frame_all", C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), sz, vp, C.c_int)
     sig("svo_set_uniforms", C.c_int, vp, C.POINTER(Uniforms))
     sig("svo_render", C.c_int, vp, u32, u32, u32, u32, u32, u32, vp, vp)
     sig("svo_render_host", C.c_int, vp, u32, u32, u32, u32, u32, u32, vp, vp)

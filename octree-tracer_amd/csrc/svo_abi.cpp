@@ -10,85 +10,24 @@
 #include <string>
 #include <vector>
 
-#include "svo_device.h"
-#include "svo_hip.h"
+#include "svo_ctx.h"
 
-struct svo_ctx {
-    int device = 0;
-    int num_cus = 256;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    // node buffer (render.rs:53-61)
-    uint32_t *nodes = nullptr;
-    size_t capacity = 0;
-    bool nodes_owned = false;
-    bool top_dirty = true;
-    uint64_t nodes_version = 0;  // bumped whenever the node buffer may have changed
-    uint32_t *top_table = nullptr;
-    uint32_t *status = nullptr;        // device error word
-    uint32_t *defer_buf = nullptr;     // {strip counter, deferred count, deferred item indices...}
-    size_t defer_items = 0;
-    // scan lists (compute.rs:46-64): slot 0 = count
-    uint32_t *scan_sub = nullptr, *scan_unsub = nullptr;
-    size_t scan_capacity = 0;
-    // host staging for svo_render_host
-    void *stage = nullptr;
-    size_t stage_bytes = 0;
-    svo_uniforms uniforms{};
-    bool have_uniforms = false;
-    // options
-    int variant = SVO_VARIANT_STACK;
-    int grid_blocks = 0;
-    uint32_t refill_min = 16;
-    bool scan_clears = false;
-    int fused_shadows = 2;  // 0: off, 1: on, 2: by frame size and tree depth (see trace_common)
-    void *scatter_buf = nullptr;
-    size_t scatter_bytes = 0;
-    uint32_t prio_steps = 0;
-    uint32_t block_w_log2 = 3;  // 64-pixel blocks of 8x8
-    uint32_t tree_depth = 16;  // caller's bound on the octree depth (the reference's Settings.octree_depth)
-    // scheduling feedback (strip order from an earlier frame of the same work layout); slot 1: shadow rays
-    struct Sched {
-        uint8_t *cost = nullptr;
-        uint8_t *cls_now = nullptr;  // launches with a skip mask: this frame's classes (0xFF = strip without a ray)
-        uint32_t *order = nullptr;
-        size_t cap = 0;
-        bool valid = false;
-        uint32_t age = 0;
-        svo::WorkDesc key{};
-        // what the schedule was measured on: while camera and tree stay the same it stays exact and is not rebuilt
-        svo_uniforms built_uniforms{};
-        uint64_t built_nodes_version = 0;
-    };
-    Sched sched[2];
-    bool schedule = true;
-    uint32_t sched_period = 2;  // frames between schedule rebuilds (tools/perf_probe.py --motion: 2 keeps the gain under camera motion)
-    int frame_parity = 0;
-    // shading pass scratch (svo_render with rgba_out)
-    void *shade_hits = nullptr, *shade_aux = nullptr, *shade_rays = nullptr, *shade_shadow = nullptr, *shade_skip = nullptr;
-    size_t shade_hits_bytes = 0, shade_aux_bytes = 0, shade_rays_bytes = 0, shade_shadow_bytes = 0, shade_skip_bytes = 0;
-    uint32_t *debug_buf = nullptr;  // caller-provided device buffer for the per-wave timeline (diagnostics)
-    uint32_t strip_items = 64;
-    bool dynamic_strips = true;
-    // launch timing: a ring of (start, stop) event pairs recorded around trace launches
-    std::vector<hipEvent_t> ev;  // 2 per slot
-    size_t ev_slots = 0, ev_count = 0;
-    std::string err;
-};
+int svo_fail(svo_ctx *ctx, int code, const char *what) {
+    if (ctx) ctx->err = what;
+    return code;
+}
+
+int svo_fail_hip(svo_ctx *ctx, hipError_t e, const char *what) {
+    if (ctx) ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+    return SVO_ERR_HIP;
+}
 
 namespace {
 
 constexpr size_t kScanCapacity = 1024000;  // adaptive.rs:3-4
 
-int fail(svo_ctx *ctx, int code, const char *what) {
-    if (ctx) ctx->err = what;
-    return code;
-}
-
-int fail_hip(svo_ctx *ctx, hipError_t e, const char *what) {
-    if (ctx) ctx->err = std::string(what) + ": " + hipGetErrorString(e);
-    return SVO_ERR_HIP;
-}
+int fail(svo_ctx *ctx, int code, const char *what) { return svo_fail(ctx, code, what); }
+int fail_hip(svo_ctx *ctx, hipError_t e, const char *what) { return svo_fail_hip(ctx, e, what); }
 
 #define HIP_TRY(ctx, expr)                                   \
     do {                                                     \
@@ -101,10 +40,54 @@ int bind(svo_ctx *ctx) {
     return SVO_OK;
 }
 
+// ---- node store (svo_ctx.h) ----
+// Reads issued by this context from now on come after the store's last write, whichever context's stream it ran on.
+int order_after_last_write(svo_ctx *ctx) {
+    svo_node_store *st = ctx->store;
+    if (st->last_write && st->last_writer != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, st->last_write, 0));
+    return SVO_OK;
+}
+
+// A write to the store's words has been enqueued on this context's stream (or, `on_stream` false, may happen behind
+// the library's back through a pointer the caller holds): every context bound to the store rebuilds what it derived.
+int note_write(svo_ctx *ctx, bool on_stream) {
+    svo_node_store *st = ctx->store;
+    st->version++;
+    if (on_stream) {
+        if (!st->last_write) HIP_TRY(ctx, hipEventCreateWithFlags(&st->last_write, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(st->last_write, ctx->stream));
+        st->last_writer = ctx->stream;
+    }
+    return SVO_OK;
+}
+
+void release_store(svo_ctx *ctx) {
+    svo_node_store *st = ctx->store;
+    ctx->store = nullptr;
+    ctx->nodes = nullptr;
+    ctx->capacity = 0;
+    ctx->top_version = 0;
+    if (!st || --st->refs > 0) return;
+    (void)hipSetDevice(st->device);
+    if (st->nodes && st->owned) (void)hipFree(st->nodes);
+    if (st->pairs) (void)hipFree(st->pairs);
+    if (st->last_write) (void)hipEventDestroy(st->last_write);
+    delete st;
+}
+
+void adopt_store(svo_ctx *ctx, svo_node_store *st) {
+    ctx->store = st;
+    ctx->nodes = st->nodes;
+    ctx->capacity = st->capacity;
+    ctx->top_version = 0;
+}
+
 int ensure_top_table(svo_ctx *ctx) {
-    if (!ctx->top_dirty) return SVO_OK;
+    if (ctx->top_version == ctx->store->version) return SVO_OK;
+    int rc = order_after_last_write(ctx);
+    if (rc) return rc;
     HIP_TRY(ctx, svo::launch_build_top_table(ctx->nodes, (uint32_t)ctx->capacity, ctx->top_table, ctx->stream));
-    ctx->top_dirty = false;
+    ctx->top_version = ctx->store->version;
     return SVO_OK;
 }
 
@@ -119,8 +102,14 @@ struct TraceOpts {
 int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo_hit *hits, const TraceOpts &opt) {
     int rc = bind(ctx);
     if (rc) return rc;
-    if (ctx->variant == SVO_VARIANT_STACK) {
+    // the kernel that runs: STACK resolves the levels its integer path codes cover (SVO_OPT_TREE_DEPTH says how deep the
+    // caller's tree may be); deeper trees, and the debug view that reads counter bits, take the general RESTART kernel
+    const bool want_stack = ctx->variant == SVO_VARIANT_STACK && ctx->tree_depth <= (uint32_t)svo::stack_max_depth(true);
+    if (want_stack) {
         rc = ensure_top_table(ctx);
+        if (rc) return rc;
+    } else {
+        rc = order_after_last_write(ctx);
         if (rc) return rc;
     }
     svo::WorkDesc wd = work;
@@ -145,7 +134,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     const bool counting = (work.mode != 2 || opt.count_rays) && !(ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE);
     a.count_nodes = counting ? ctx->nodes : nullptr;
     const bool debug_hits = (ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE) && (ctx->uniforms.flags & SVO_F_SHOW_HITS);
-    const bool stack = ctx->variant == SVO_VARIANT_STACK && !debug_hits;
+    const bool stack = want_stack && !debug_hits;
     a.shadow_hits = stack ? opt.shadow_out : nullptr;
     const uint32_t n_strips = (wd.n_items + 63u) / 64u;
     const bool schedule = ctx->schedule && n_strips <= svo::kMaxScheduledStrips;
@@ -183,6 +172,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     li.num_cus = ctx->num_cus;
     li.strip_items = ctx->strip_items;
     li.deep_stack = ctx->tree_depth > (uint32_t)svo::stack_max_depth(false);
+    li.occupancy = ctx->occupancy;
     if (stack && ctx->defer_items < wd.n_items) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->defer_buf) (void)hipFree(ctx->defer_buf);
@@ -217,7 +207,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         // count does not depend on the order it was traced in, so a schedule measured on this camera and tree stays
         // exact as long as both stay put (caller-supplied rays cannot be compared: they always count as moving; 64
         // frames is a backstop for node buffers written behind this context's back).
-        const bool same_input = (wd.mode != 2 || opt.sched_slot == 1) && sc.built_nodes_version == ctx->nodes_version &&
+        const bool same_input = (wd.mode != 2 || opt.sched_slot == 1) && sc.built_nodes_version == ctx->store->version &&
                                 memcmp(&sc.built_uniforms, &ctx->uniforms, sizeof(svo_uniforms)) == 0 && sc.age < 64;
         const bool rebuild = schedule && (!sc.valid || (!same_input && sc.age + 1 >= ctx->sched_period));
         // (a launch with a skip mask builds its lists before the trace, every frame: here only the costs are measured)
@@ -229,7 +219,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
             sc.valid = true;
             sc.age = 0;
             sc.built_uniforms = ctx->uniforms;
-            sc.built_nodes_version = ctx->nodes_version;
+            sc.built_nodes_version = ctx->store->version;
         } else if (schedule) {
             sc.age++;
         }
@@ -245,7 +235,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
 bool fuse_shadow_rays(const svo_ctx *ctx, size_t n_pixels) {
     const bool want = ctx->fused_shadows == 1 ||
                       (ctx->fused_shadows == 2 && (ctx->tree_depth > (uint32_t)svo::stack_max_depth(false) || n_pixels >= (1u << 22)));
-    if (!want || ctx->variant != SVO_VARIANT_STACK) return false;
+    if (!want || ctx->variant != SVO_VARIANT_STACK || ctx->tree_depth > (uint32_t)svo::stack_max_depth(true)) return false;
     const float *sd = ctx->uniforms.sun_dir;
     const float sl = sqrtf((sd[0] * sd[0] + sd[1] * sd[1]) + sd[2] * sd[2]);
     for (int k = 0; k < 3; k++) {
@@ -475,7 +465,8 @@ int svo_ctx_destroy(svo_ctx *ctx) {
     if (!ctx) return SVO_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->nodes && ctx->nodes_owned) (void)hipFree(ctx->nodes);
+    svo_comm_release(ctx);
+    release_store(ctx);
     if (ctx->top_table) (void)hipFree(ctx->top_table);
     if (ctx->status) (void)hipFree(ctx->status);
     if (ctx->defer_buf) (void)hipFree(ctx->defer_buf);
@@ -554,12 +545,14 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
             return SVO_OK;
         case SVO_OPT_TREE_DEPTH:
             if (value < 1 || value > 31) return fail(ctx, SVO_ERR_ARG, "tree depth must be 1..31");
-            ctx->tree_depth = (uint32_t)value;
-            if (value > svo::stack_max_depth(true) && ctx->variant == SVO_VARIANT_STACK)
-                ctx->variant = SVO_VARIANT_RESTART;  // deeper than the integer path codes resolve: general kernel
+            ctx->tree_depth = (uint32_t)value;  // (which kernel that means is decided per launch, see trace_launch)
+            return SVO_OK;
+        case SVO_OPT_PAIR_TABLE:
+            if (value < 0 || value > 1) return fail(ctx, SVO_ERR_ARG, "pair table: 0 (off) or 1 (on)");
+            ctx->use_pairs = (int)value;
             return SVO_OK;
         case SVO_OPT_DEBUG_BUFFER:
-            ctx->debug_buf = (uint32_t *)(uintptr_t)value;  // device pointer, >= 16 B per wave of the grid; 0 = off
+            ctx->debug_buf = (uint32_t *)(uintptr_t)value;  // device pointer, 64 B per wave of the grid; 0 = off
             return SVO_OK;
         case SVO_OPT_BLOCK_SHAPE:
             if (value < 0 || value > 6) return fail(ctx, SVO_ERR_ARG, "block width log2 must be 0..6");
@@ -581,6 +574,7 @@ int svo_sync(svo_ctx *ctx) {
     int rc = bind(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));  // frame-end gathers in flight
     // surface device-side errors raised by trace kernels
     uint32_t st = 0;
     HIP_TRY(ctx, hipMemcpy(&st, ctx->status, sizeof(st), hipMemcpyDeviceToHost));
@@ -604,17 +598,22 @@ int svo_nodes_alloc(svo_ctx *ctx, size_t capacity_words) {
     int rc = bind(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->nodes && ctx->nodes_owned) (void)hipFree(ctx->nodes);
-    ctx->nodes = nullptr;
-    ctx->capacity = 0;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->nodes, capacity_words * sizeof(uint32_t)));
-    ctx->nodes_owned = true;
-    ctx->capacity = capacity_words;
+    release_store(ctx);  // (contexts that share the old store keep it alive)
+    uint32_t *words = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&words, capacity_words * sizeof(uint32_t)));
+    svo_node_store *st = new (std::nothrow) svo_node_store();
+    if (!st) {
+        (void)hipFree(words);
+        return fail(ctx, SVO_ERR_HIP, "out of host memory");
+    }
+    st->device = ctx->device;
+    st->nodes = words;
+    st->capacity = capacity_words;
+    st->owned = true;
+    adopt_store(ctx, st);
     // Octree::expanded zero-fills the tail (octree.rs:143-148)
     HIP_TRY(ctx, hipMemsetAsync(ctx->nodes, 0, capacity_words * sizeof(uint32_t), ctx->stream));
-    ctx->top_dirty = true;
-    ctx->nodes_version++;
-    return SVO_OK;
+    return note_write(ctx, true);
 }
 
 int svo_nodes_bind_device(svo_ctx *ctx, uint32_t *device_words, size_t capacity_words) {
@@ -624,13 +623,37 @@ int svo_nodes_bind_device(svo_ctx *ctx, uint32_t *device_words, size_t capacity_
     int rc = bind(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->nodes && ctx->nodes_owned) (void)hipFree(ctx->nodes);
-    ctx->nodes = device_words;
-    ctx->nodes_owned = false;
-    ctx->capacity = capacity_words;
-    ctx->top_dirty = true;
-    ctx->nodes_version++;
+    release_store(ctx);
+    svo_node_store *st = new (std::nothrow) svo_node_store();
+    if (!st) return fail(ctx, SVO_ERR_HIP, "out of host memory");
+    st->device = ctx->device;
+    st->nodes = device_words;
+    st->capacity = capacity_words;
+    st->owned = false;
+    adopt_store(ctx, st);
     return SVO_OK;
+}
+
+int svo_nodes_share(svo_ctx *ctx, svo_ctx *owner) {
+    if (!ctx || !owner) return SVO_ERR_ARG;
+    if (!owner->store) return fail(ctx, SVO_ERR_STATE, "the owner has no node buffer (svo_nodes_alloc / svo_nodes_bind_device)");
+    if (owner->device != ctx->device) return fail(ctx, SVO_ERR_ARG, "contexts on different devices cannot share a node buffer");
+    if (ctx->store == owner->store) return SVO_OK;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    release_store(ctx);
+    owner->store->refs++;
+    adopt_store(ctx, owner->store);
+    return SVO_OK;
+}
+
+int svo_nodes_invalidate(svo_ctx *ctx) {
+    if (!ctx) return SVO_ERR_ARG;
+    if (!ctx->store) return fail(ctx, SVO_ERR_STATE, "svo_nodes_alloc / svo_nodes_bind_device not called");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    return note_write(ctx, true);
 }
 
 int svo_nodes_write(svo_ctx *ctx, size_t word_offset, const uint32_t *host_words, size_t n) {
@@ -643,9 +666,7 @@ int svo_nodes_write(svo_ctx *ctx, size_t word_offset, const uint32_t *host_words
     if (n)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->nodes + word_offset, host_words, n * sizeof(uint32_t), hipMemcpyHostToDevice,
                                     ctx->stream));
-    ctx->top_dirty = true;
-    ctx->nodes_version++;
-    return SVO_OK;
+    return note_write(ctx, true);
 }
 
 int svo_nodes_scatter(svo_ctx *ctx, const uint32_t *indices, const uint32_t *host_words, size_t n) {
@@ -662,9 +683,7 @@ int svo_nodes_scatter(svo_ctx *ctx, const uint32_t *indices, const uint32_t *hos
     HIP_TRY(ctx, hipMemcpyAsync(d_idx, indices, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_val, host_words, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, svo::launch_scatter(ctx->nodes, (uint32_t)ctx->capacity, d_idx, d_val, (uint32_t)n, ctx->stream));
-    ctx->top_dirty = true;
-    ctx->nodes_version++;
-    return SVO_OK;
+    return note_write(ctx, true);
 }
 
 int svo_nodes_read(svo_ctx *ctx, size_t word_offset, uint32_t *host_words, size_t n) {
@@ -686,8 +705,7 @@ int svo_nodes_device_ptr(svo_ctx *ctx, uint32_t **out, size_t *capacity_words) {
     if (!ctx || !out) return SVO_ERR_ARG;
     *out = ctx->nodes;
     if (capacity_words) *capacity_words = ctx->capacity;
-    ctx->top_dirty = true;
-    ctx->nodes_version++;  // the caller may write through the pointer
+    if (ctx->store) return note_write(ctx, false);  // the caller may write through the pointer
     return SVO_OK;
 }
 

@@ -51,7 +51,7 @@ struct TraceArgs {
     uint32_t *count_nodes;      // writable alias of nodes when hit counters are live (pause_adaptive off), else nullptr
     const uint32_t *order;      // STACK, optional: schedule built by strip_order_kernel (8 lengths + 8 lists)
     uint32_t order_cap;         // entries reserved per list
-    uint32_t *debug;            // optional: 8 words per wave (start, queue-dry, end ticks of 10 ns, rounds, active-lane sum, ...)
+    uint32_t *debug;            // optional: 16 words per wave (start, queue-dry, end ticks of 10 ns, rounds, active-lane sum, ..., phase cycles)
     const uint8_t *skip;        // mode 2, optional: one byte per ray; non-zero = no ray here, its (all-zero) record is already written
     svo_hit *shadow_hits;       // STACK, optional (fused shadow rays): the lane that finishes a primary ray with a hit goes on with that
                                 // pixel's shadow ray (shader.wgsl:275-280) and writes its record here; pixels without one get zeros
@@ -61,6 +61,7 @@ struct LaunchInfo {
     int variant;
     int grid_blocks;         // 0 = auto
     int num_cus;
+    int *occupancy;          // STACK: the context's cache of resident workgroups per CU, one slot per instantiation
     bool deep_stack;         // STACK: 19-level ancestor stack (trees deeper than 16 levels)
     uint32_t strip_items;    // STACK: pixel slots a wave claims at a time (multiple of 64)
     uint32_t *counters;      // STACK: kCounterWords claim-counter words, zero when a frame starts

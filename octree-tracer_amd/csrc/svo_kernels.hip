@@ -613,6 +613,9 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
     // optional per-wave timeline (diagnostic builds of the host set a.debug): start, queue-dry, end in 10 ns ticks
     uint64_t t_begin = 0, t_dry = 0;
     uint32_t n_rounds = 0, dbg_active = 0, dbg_iters = 0, dbg_refills = 0, dbg_gens = 0;
+    // phase clocks of the timeline build (shader cycles, s_memtime): refill / descent / step, and the descent's shape
+    uint64_t c_mark = 0;
+    uint32_t c_refill = 0, c_desc = 0, c_step = 0, c_gen = 0, dbg_desc_iters = 0, dbg_desc_lanes = 0, dbg_desc_rounds = 0, dbg_desc_start = 0;
     if (DBG) t_begin = __builtin_amdgcn_s_memrealtime();
 
     // per-lane ray state
@@ -708,6 +711,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
     };
 
     for (;;) {
+        if (DBG) c_mark = __builtin_amdgcn_s_memtime();
         // ---- 1. refill idle lanes from the ray pool (ballot compaction) ----
         // Common case first and cheap: fewer than refill_min idle lanes -> straight on.  (refill_min <= 64, so a wave
         // without active lanes always takes the slow path, where the exit test lives.)
@@ -741,6 +745,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                 if (DBG) dbg_refills += 1;
                 if (pool_n == 0u) {
                     if (DBG) dbg_gens += 1;
+                    const uint64_t c_g0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
                     // -- generate the next (up to) 64 rays, all lanes --
                     const uint32_t q = next + lane;
                     bool alive = false;
@@ -811,6 +816,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                         }
                     }
                     if (DBG && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
+                    if (DBG) c_gen += (uint32_t)(__builtin_amdgcn_s_memtime() - c_g0);
                 }
                 // -- idle lanes first write the record of the ray they finished, then take rays pool_i .. --
                 if (st & ST_PENDING) flush_record(true);
@@ -861,6 +867,12 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
         if (DBG) {  // per-wave timeline build only (SVO_OPT_DEBUG_BUFFER): the default instantiation carries none of this
             n_rounds += 1;
             dbg_active += (uint32_t)__popcll(__ballot((st & ST_ACTIVE) != 0u));
+            const uint64_t now = __builtin_amdgcn_s_memtime();
+            c_refill += (uint32_t)(now - c_mark);
+            c_mark = now;
+            const uint32_t nd = (uint32_t)__popcll(__ballot(st >= (ST_ACTIVE | ST_DESC)));
+            dbg_desc_start += nd;
+            dbg_desc_rounds += nd ? 1u : 0u;
         }
 
         // ---- 2. descent: one dependent word per level below the restart level ----
@@ -873,6 +885,13 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
             // straight-line body, one exit test: the push also happens on the exiting iteration (it lands in the
             // slot below the leaf, which no restart reads; the stack has one spare row for an exit at level SMAX)
             do {
+                if (DBG) {
+                    const uint64_t in_loop = __ballot(true);
+                    if (lane == (uint32_t)__ffsll((unsigned long long)in_loop) - 1u) {  // (tallies summed over lanes at the end)
+                        dbg_desc_iters += 1u;
+                        dbg_desc_lanes += (uint32_t)__popcll(in_loop);
+                    }
+                }
                 // sh -= 1 (level being read: D - sh); child = x << 2 | y << 1 | z; byte offset = (nidx + child) << 2.
                 // Three-operand forms the compiler does not pick by itself, in ONE asm statement (the compiler pads every
                 // inline-asm statement with an s_nop, and keeping the decrement inside saves a copy of the counter)
@@ -899,6 +918,11 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
             st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
         }
 
+        if (DBG) {
+            const uint64_t now = __builtin_amdgcn_s_memtime();
+            c_desc += (uint32_t)(now - c_mark);
+            c_mark = now;
+        }
         // ---- 3. hit test / DDA step (shader.wgsl:215-244), clean rays, grid units ----
         if ((int32_t)st < 0) {  // ST_ACTIVE
             const uint32_t L = (st >> ST_L_SHIFT) & 31u;
@@ -999,6 +1023,14 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                 restart_at(r);
             }
         }
+        if (DBG) c_step += (uint32_t)(__builtin_amdgcn_s_memtime() - c_mark);
+    }
+    if (DBG) {  // wave totals of the per-lane tallies
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            dbg_desc_iters += (uint32_t)__shfl_xor((int)dbg_desc_iters, o);
+            dbg_desc_lanes += (uint32_t)__shfl_xor((int)dbg_desc_lanes, o);
+        }
     }
     if (DBG) {  // the rays that finish last: their step counts tell whether the tail is long rays or late starts
         uint32_t last = (st & ST_PENDING) ? (st & 0xFFu) : 0u;
@@ -1009,7 +1041,15 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
     if (st & ST_PENDING) flush_record(false);
     if (DBG && lane == 0) {
         uint64_t t_end = __builtin_amdgcn_s_memrealtime();
-        uint32_t *d = a.debug + 8u * wave_id;
+        uint32_t *d = a.debug + 16u * wave_id;
+        d[8] = c_refill;         // shader cycles in the refill section (ray generation included)
+        d[9] = c_desc;           // ... in the descent loop
+        d[10] = c_step;          // ... in the step section
+        d[11] = c_gen;           // ... generating rays (part of d[8])
+        d[12] = dbg_desc_iters;  // descent-loop iterations of the wave (one dependent load each)
+        d[13] = dbg_desc_lanes;  // lanes inside the loop, summed over its iterations
+        d[14] = dbg_desc_rounds; // rounds in which any lane descended
+        d[15] = dbg_desc_start;  // lanes that started a descent, summed over rounds
         d[0] = (uint32_t)t_begin;
         d[1] = (uint32_t)(t_dry ? t_dry : t_end);
         d[2] = (uint32_t)t_end;
@@ -1462,8 +1502,8 @@ static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipS
                                                       : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false>));
     size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
                                 (args.count_nodes ? kTopAuxEntries : 0)) * sizeof(uint32_t);
-    static int occupancy[4] = {0, 0, 0, 0};  // [fused shadows?][counting instantiation?]
-    int &blocks_per_cu = occupancy[(shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
+    // cached per context (= per device): [deep stack?][fused shadows?][counting instantiation?]
+    int &blocks_per_cu = li.occupancy[(NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
     if (blocks_per_cu == 0) {
         int n = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kStackBlock, lds_bytes);

@@ -4,7 +4,7 @@ import ctypes as C
 
 from ._lib import SvoError, lib
 
-OPT_VARIANT, OPT_TIMING, OPT_GRID_BLOCKS, OPT_REFILL_MIN, OPT_STRIP_ITEMS, OPT_DYNAMIC_STRIPS, OPT_PRIO_STEPS, OPT_DEBUG_BUFFER, OPT_SCHEDULE, OPT_TREE_DEPTH, OPT_BLOCK_SHAPE, OPT_SCAN_CLEARS_COUNTERS, OPT_FUSED_SHADOWS = range(13)
+OPT_VARIANT, OPT_TIMING, OPT_GRID_BLOCKS, OPT_REFILL_MIN, OPT_STRIP_ITEMS, OPT_DYNAMIC_STRIPS, OPT_PRIO_STEPS, OPT_DEBUG_BUFFER, OPT_SCHEDULE, OPT_TREE_DEPTH, OPT_BLOCK_SHAPE, OPT_SCAN_CLEARS_COUNTERS, OPT_FUSED_SHADOWS, OPT_PAIR_TABLE = range(14)
 VARIANT_RESTART, VARIANT_STACK = 0, 1
 
 
@@ -56,6 +56,41 @@ class Gpu:
         n = C.c_size_t()
         self.check(lib().svo_timing_collect(self._h, buf.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n)))
         return buf[:n.value].copy()
+
+    # ---- multi-GPU frame end: RCCL behind the C ABI (svo_comm_*, svo_gather_frame) ----
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes rank 0 hands to the other ranks (ncclGetUniqueId)"""
+        buf = (C.c_uint8 * 128)()
+        rc = lib().svo_comm_unique_id(buf)
+        if rc != 0:
+            raise SvoError(f"svo_comm_unique_id failed with status {rc} (librccl missing?)")
+        return bytes(buf)
+
+    def comm_init_rank(self, unique_id, world, rank):
+        """collective: every rank's context, with rank 0's id (one process per GPU)"""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self.check(lib().svo_comm_init_rank(self._h, buf, world, rank))
+
+    @staticmethod
+    def comm_init_all(gpus):
+        """one process driving several devices: gpus[r] becomes rank r (ncclCommInitAll)"""
+        arr = (C.c_void_p * len(gpus))(*[g._h for g in gpus])
+        rc = lib().svo_comm_init_all(len(gpus), arr)
+        if rc != 0:
+            raise SvoError(f"status {rc}: {lib().svo_last_error(gpus[0]._h).decode()}")
+
+    def comm_destroy(self):
+        self.check(lib().svo_comm_destroy(self._h))
+
+    def gather_frame(self, send, recv_on_root=None, root=0):
+        """this rank's part of the frame-end gather, on the context's stream: tensor `send` -> recv_on_root[rank] on root"""
+        self.check(lib().svo_gather_frame(self._h, send.data_ptr(), send.numel() * send.element_size(),
+                                          recv_on_root.data_ptr() if recv_on_root is not None else None, root))
+
+    def gather_wait(self):
+        """the context's stream waits for the gathers issued so far"""
+        self.check(lib().svo_gather_wait(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

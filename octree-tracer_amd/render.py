@@ -38,13 +38,14 @@ class Render:
     @classmethod
     def share_nodes(cls, gpu, other):
         """A second Render on another context (its own stream) over the SAME device node buffer (zero copy):
-        svo_nodes_bind_device.  Used to keep more than one frame in flight."""
+        svo_nodes_share.  Used to keep more than one frame in flight.  The contexts share the buffer's generation counter:
+        a write through either one (write_nodes, scatter_nodes, the adaptive loop) makes every one of them rebuild its top
+        table and schedule before its next trace, which also waits on the device for that write.  A write does not wait
+        for frames other lanes still have in flight -- sync them first."""
         self = cls.__new__(cls)
         self.gpu, self.size = gpu, other.size
-        ptr, cap = C.c_void_p(), C.c_size_t()
-        other.gpu.check(lib().svo_nodes_device_ptr(other.gpu._h, C.byref(ptr), C.byref(cap)))
-        gpu.check(lib().svo_nodes_bind_device(gpu._h, ptr, cap.value))
-        self.capacity, self.node_length = cap.value, other.node_length
+        gpu.check(lib().svo_nodes_share(gpu._h, other.gpu._h))
+        self.capacity, self.node_length = other.capacity, other.node_length
         self.uniforms = Uniforms()
         C.memmove(C.byref(self.uniforms), C.byref(other.uniforms), C.sizeof(Uniforms))
         self.upload_uniforms()

@@ -73,10 +73,15 @@ class FramePipeline:
     buffers); drain() completes what is in flight and returns the last frame."""
 
     def __init__(self, trace, width, height, tile_w, tile_h, rank, world, device, group=None, streams=None, assemble=None,
-                 pack=None):
+                 pack=None, gather=None):
         """assemble (optional, rank 0): one callable per lane, `assemble(gathered, out) -> out`, that un-permutes a gathered
         frame on the lane's stream (Render.assemble_tiles: one kernel, a few microseconds of host time); without it the
         generic torch expression assemble_frame() is used."""
+        # gather (optional): one pair of callables per lane, (`gather(send, recv_on_root)`, `wait()`): the first enqueues this
+        # rank's part of the frame-end gather behind the lane's stream (Gpu.gather_frame: RCCL behind the C ABI,
+        # svo_gather_frame), the second makes the lane's stream wait for it (Gpu.gather_wait).  Without it the exchange is
+        # torch.distributed's gather on the default process group (RCCL as well on the GPU box, gloo in the CPU tests)
+        self.gather = list(gather) if gather is not None else None
         self.traces = list(trace) if isinstance(trace, (list, tuple)) else [trace]
         self.assemble = list(assemble) if assemble is not None else None
         # pack: what goes over the links is the 12-byte wire form of the records.  True = the torch expression
@@ -110,7 +115,10 @@ class FramePipeline:
 
     def _finish(self, b):
         if self.work[b] is not None:
-            self.work[b].wait()  # the current stream waits for the collective
+            if self.work[b] is True:
+                self.gather[b % len(self.traces)][1]()  # C ABI: the lane's stream waits for the lane's gathers
+            else:
+                self.work[b].wait()  # the current stream waits for the collective
             self.work[b] = None
             if self.rank == 0:
                 if self.assemble:
@@ -131,7 +139,10 @@ class FramePipeline:
             else:
                 self.pack[lane](self.local[b], self.wire[b])
             send = self.wire[b]
-        if self.rank == 0:
+        if self.gather is not None:
+            self.gather[lane][0](send, self.gathered[b] if self.rank == 0 else None)
+            self.work[b] = True
+        elif self.rank == 0:
             self.work[b] = dist.gather(send, self.recv[b], dst=0, group=self.group, async_op=True)
         else:
             self.work[b] = dist.gather(send, None, dst=0, group=self.group, async_op=True)

@@ -1,0 +1,177 @@
+"""GPU tests of the boundary's round-2 additions: shared node stores (svo_nodes_share / svo_nodes_invalidate), the RCCL
+frame gather behind the C ABI (svo_comm_*, svo_gather_frame*) with the ranks one GPU can host, the per-launch kernel
+choice under SVO_OPT_TREE_DEPTH, and bench.py starting its own ranks."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_hits_equal, set_uniforms_from_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_shared_node_buffer_sees_writes_of_the_owner(pkg, gpu, O, small_words, monu9_words):
+    """a lane that shares the owner's node buffer must rebuild its LDS top table and schedule when the
+    OWNER writes the tree.  Write a different tree through the owner, trace on the sharing lane, compare with the oracle
+    -- full upload, scatter, and svo_nodes_invalidate after a write behind the library's back."""
+    import torch
+    gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+    cap = max(monu9_words.size, small_words.size)
+    u = O.make_uniforms(width=320, height=192, flags=O.F_PAUSE_ADAPTIVE)
+    owner = pkg.Render(gpu, (320, 192), monu9_words, capacity=cap)
+    set_uniforms_from_oracle(owner, u)
+    stream = torch.cuda.Stream()
+    g2 = pkg.Gpu(0, stream=stream.cuda_stream)
+    try:
+        g2.set_option(pkg.gpu.OPT_VARIANT, 1)
+        lane = pkg.Render.share_nodes(g2, owner)
+        set_uniforms_from_oracle(lane, u)
+        for _ in range(2):  # second frame: the lane's schedule is built
+            hits = lane.render()
+            g2.sync()  # (the lane runs on its own non-blocking stream: torch's copy below would not wait for it)
+            got = pkg.render.hits_to_numpy(hits)
+        assert_hits_equal(got, O.trace_frame(monu9_words, u, threads=8), "shared lane, first tree")
+        # 1. whole-array upload through the owner (the reference's per-frame write_buffer, app.rs:113-118)
+        padded = np.zeros(cap, dtype=np.uint32)
+        padded[:small_words.size] = small_words
+        owner.write_nodes(padded)
+        hits = lane.render()
+        g2.sync()
+        got = pkg.render.hits_to_numpy(hits)
+        assert_hits_equal(got, O.trace_frame(padded, u, threads=8), "shared lane after the owner's upload")
+        # 2. incremental upload through the owner: back to the first tree, only the words that differ
+        back = np.zeros(cap, dtype=np.uint32)
+        back[:monu9_words.size] = monu9_words
+        idx = np.flatnonzero(back != padded).astype(np.uint32)
+        owner.scatter_nodes(idx, back[idx])
+        hits = lane.render()
+        g2.sync()
+        got = pkg.render.hits_to_numpy(hits)
+        assert_hits_equal(got, O.trace_frame(back, u, threads=8), "shared lane after the owner's scatter")
+        # 3. a write behind the library's back (torch copy into the buffer) + svo_nodes_invalidate on the writer's context
+        ptr, capw = C.c_void_p(), C.c_size_t()
+        gpu.check(pkg._lib.lib().svo_nodes_device_ptr(gpu._h, C.byref(ptr), C.byref(capw)))
+        assert capw.value == cap
+        dev = torch.from_numpy(padded.view(np.int32)).cuda()
+        gpu.check(pkg._lib.lib().svo_sync(gpu._h))
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so.7")  # (already loaded by torch: same instance)
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        assert hip.hipMemcpy(ptr, dev.data_ptr(), cap * 4, 3) == 0  # device to device
+        gpu.check(pkg._lib.lib().svo_nodes_invalidate(gpu._h))
+        hits = lane.render()
+        g2.sync()
+        got = pkg.render.hits_to_numpy(hits)
+        assert_hits_equal(got, O.trace_frame(padded, u, threads=8), "shared lane after svo_nodes_invalidate")
+        # the owner, too
+        got = pkg.render.hits_to_numpy(owner.render())
+        gpu.sync()
+        assert_hits_equal(got, O.trace_frame(padded, u, threads=8), "owner after svo_nodes_invalidate")
+        # the buffer outlives its first owner
+        del owner
+    finally:
+        g2.close()
+
+
+def test_tree_depth_option_raised_and_lowered(pkg, gpu, O, monu9_words):
+    """raising SVO_OPT_TREE_DEPTH beyond what the integer path codes resolve selects the general kernel for
+    that launch only; lowering it again returns to the STACK kernel (seen through the per-launch timing: the general kernel
+    takes several times as long on this frame) with identical records throughout."""
+    gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+    u = O.make_uniforms(width=960, height=544, flags=O.F_PAUSE_ADAPTIVE)
+    render = pkg.Render(gpu, (960, 544), monu9_words, capacity=monu9_words.size)
+    set_uniforms_from_oracle(render, u)
+    want = O.trace_frame(monu9_words, u, threads=8)
+    gpu.set_option(pkg.gpu.OPT_TIMING, 4)
+    ms = {}
+    try:
+        for depth in (16, 28, 16, 20, 16):
+            gpu.set_option(pkg.gpu.OPT_TREE_DEPTH, depth)
+            for _ in range(3):
+                got = pkg.render.hits_to_numpy(render.render())
+            ms.setdefault(depth, []).append(gpu.last_render_ms())
+            gpu.sync()
+            assert_hits_equal(got, want, f"tree_depth {depth}")
+    finally:
+        gpu.set_option(pkg.gpu.OPT_TREE_DEPTH, 16)
+        gpu.set_option(pkg.gpu.OPT_TIMING, 0)
+    assert max(ms[16]) < 0.8 * ms[28][0], f"depth 16 after 28 should be back on the STACK kernel: {ms}"
+
+
+def test_comm_abi_single_rank(pkg, gpu):
+    """svo_comm_unique_id / svo_comm_init_rank / svo_gather_frame / svo_gather_wait / svo_comm_destroy and the single-process
+    forms svo_comm_init_all / svo_gather_frame_all with the one rank a one-GPU box can host: the gather is a device copy
+    through RCCL, ordered behind the context's stream."""
+    import torch
+    L = pkg._lib.lib()
+    n_pad, tile, world = 5, 64 * 8, 1
+    send = torch.arange(n_pad * tile * 3, dtype=torch.int32, device="cuda").reshape(n_pad, tile, 3)
+    recv = torch.zeros((world, n_pad, tile, 3), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    # gather without a communicator is a state error, not a crash
+    with pytest.raises(pkg.SvoError):
+        gpu.gather_frame(send, recv, 0)
+    uid = pkg.Gpu.comm_unique_id()
+    assert len(uid) == 128
+    gpu.comm_init_rank(uid, 1, 0)
+    with pytest.raises(pkg.SvoError):
+        gpu.gather_frame(send, recv, 3)  # root outside the communicator
+    for k in range(3):  # three "frames": each gather ordered behind the write of its send buffer on the ctx stream
+        send.add_(1)
+        gpu.gather_frame(send, recv, 0)
+        gpu.gather_wait()
+        gpu.sync()
+        assert torch.equal(recv[0], send), f"frame {k}"
+    gpu.comm_destroy()
+    gpu.comm_destroy()  # idempotent
+    # single-process form
+    pkg.Gpu.comm_init_all([gpu])
+    recv.zero_()
+    ctxs = (C.c_void_p * 1)(gpu._h)
+    sends = (C.c_void_p * 1)(send.data_ptr())
+    gpu.check(L.svo_gather_frame_all(1, ctxs, sends, send.numel() * 4, recv.data_ptr(), 0))
+    gpu.gather_wait()
+    gpu.sync()
+    assert torch.equal(recv[0], send)
+    # two contexts on the same device cannot form a single-process clique
+    g2 = pkg.Gpu(0)
+    try:
+        with pytest.raises(pkg.SvoError):
+            pkg.Gpu.comm_init_all([gpu, g2])
+    finally:
+        g2.close()
+    gpu.comm_destroy()
+
+
+def _bench(args, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_starts_its_own_ranks(pkg, gpu):
+    """VERDICT r1 missing 1: `python bench.py --gpus 2` (no launcher) must start its ranks itself.  On a one-GPU box the two
+    ranks share the GPU (--backend gloo: validation mode); the assembled frame is checked against the oracle."""
+    line = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1", "--no-extras"])
+    assert line["n_gpus"] == 2 and line["steps"] == 4
+    assert line["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] is True
+    assert line["config"]["backend"] == "gloo"
+
+
+def test_bench_line_fields(pkg, gpu):
+    """The N = 1 line carries the fields VERDICT r1 asked for: cold frame, moving camera, the 4K frame beside the headline,
+    the measured-limiter commentary and the VALU roofline object."""
+    line = _bench(["--steps", "20", "--warmup", "3"])
+    cfg = line["config"]
+    assert cfg["frames_in_flight"] == 1 and "latency" in cfg["step_semantics"]
+    assert cfg["cold_frame_ms"] > 0 and cfg["motion_ms"] > 0 and cfg["also"]["workload"] == "terrain16_4k" and cfg["also"]["value"] > 0
+    assert line["roofline"]["bound"] == "hbm" and "traffic_source" in line["roofline"] and line["roofline"]["measured_hbm_gbs"] > 0
+    assert 0 < line["roofline_valu"]["frac"] < 1
+    assert line["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] is True
+    assert line["cpu_baseline"]["host_cores_total"] >= line["cpu_baseline"]["cores"]

@@ -1,45 +1,103 @@
-"""Diagnostic: per-wave timeline of the STACK kernel (start / work-queue-dry / end) on the bench workload."""
-import os, sys
+"""Diagnostic: per-wave timeline of the STACK kernel (start / work-queue-dry / end), shader cycles per phase (refill, ray
+generation, descent, step) and the shape of the descent loop, on the bench workload or one of the BASELINE configs.
+usage: python tools/wave_timeline.py [--scene terrain|config2|config3a|config3b] [--w 1920 --h 1080] [--json out.json]"""
+import argparse
+import json
+import os
+import sys
+
 import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import __graft_entry__ as entry
-pkg = entry.load_package()
-import torch
-W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
-cam, look = pkg.scenes.terrain_camera(0, 16)
-words = pkg.scenes.terrain(seed=0, max_depth=16, cam=cam, lod_c=1500.0, max_words=125_000_000)
-gpu = pkg.Gpu(0)
-render = pkg.Render(gpu, (W, H), words, capacity=words.size)
-render.set_flags(pause_adaptive=True, shadows=False)
-render.update(pkg.Settings(), pkg.Character(cam, look))
-dbg = torch.zeros((16384, 8), dtype=torch.int32, device="cuda")
-hits = render.alloc_hits(W * H)
-for _ in range(3):
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as entry  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="terrain")
+    ap.add_argument("--w", type=int, default=1920)
+    ap.add_argument("--h", type=int, default=1080)
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE for gpu.set_option (e.g. REFILL_MIN=8)")
+    a = ap.parse_args()
+    pkg = entry.load_package()
+    import torch
+    import config_scenes as cs
+    W, H = a.w, a.h
+    if a.scene == "terrain":
+        words, poses, _ = cs.config4(pkg)
+        pose = poses[0]
+    elif a.scene == "config2":
+        words, poses, _ = cs.config2(pkg)
+        pose = poses[1]
+    elif a.scene in ("config3a", "config3b"):
+        words, poses, _ = cs.config3(pkg)
+        pose = poses[0 if a.scene == "config3a" else 1]
+    else:
+        raise SystemExit("unknown scene")
+    gpu = pkg.Gpu(0)
+    render = pkg.Render(gpu, (W, H), words, capacity=words.size)
+    render.set_flags(pause_adaptive=True, shadows=False)
+    render.update(pkg.Settings(), pkg.Character(*pose))
+    for o in a.opt:
+        k, v = o.split("=")
+        gpu.set_option(getattr(pkg.gpu, "OPT_" + k), int(v))
+    dbg = torch.zeros((16384, 16), dtype=torch.int32, device="cuda")
+    hits = render.alloc_hits(W * H)
+    gpu.set_option(pkg.gpu.OPT_TIMING, 8)
+    for _ in range(4):
+        render.render(hits=hits)
+    ms_plain = gpu.last_render_ms()
+    gpu.sync()
+    gpu.set_option(pkg.gpu.OPT_DEBUG_BUFFER, dbg.data_ptr())
     render.render(hits=hits)
-gpu.sync()
-gpu.set_option(pkg.gpu.OPT_DEBUG_BUFFER, dbg.data_ptr())
-gpu.set_option(pkg.gpu.OPT_TIMING, 1)
-render.render(hits=hits)
-ms = gpu.last_render_ms()
-gpu.sync()
-d = dbg.cpu().numpy().view(np.uint32)
-d = d[d[:, 2] != 0]
-t0 = d[:, 0].min()
-start, dry, end = (d[:, 0] - t0) * 0.01, (d[:, 1] - t0) * 0.01, (d[:, 2] - t0) * 0.01  # us
-print(f"kernel {ms * 1e3:.1f} us, waves {len(d)}")
-pct = [0, 1, 5, 25, 50, 75, 95, 99, 100]
-print("pct       ", pct)
-print("start us  ", np.percentile(start, pct).round(1))
-print("dry   us  ", np.percentile(dry, pct).round(1))
-print("end   us  ", np.percentile(end, pct).round(1))
-print("drain us  ", np.percentile(end - dry, pct).round(1))
-print("rounds    ", np.percentile(d[:, 3], pct).round(0))
-print("us/round  ", np.percentile((end - start) / np.maximum(d[:, 3], 1), pct).round(2))
-print("active lanes per round (mean over waves):", (d[:, 4].sum() / d[:, 3].sum()).round(2), " refills/round", (d[:, 6].sum() / d[:, 3].sum()).round(3), " gens", int(d[:, 7].sum()), " total rounds", int(d[:, 3].sum()))
-print("steps of the last rays of a wave, by end-time decile:", [int(np.median(d[np.argsort(end)][i * len(d) // 10:(i + 1) * len(d) // 10, 5])) for i in range(10)])
-idx = np.argsort(end)[-8:]
-print("latest waves: id, dry, end, rounds, steps of its last ray")
-ids = np.flatnonzero(dbg.cpu().numpy().view(np.uint32)[:, 2] != 0)
-for i in idx:
-    print(int(ids[i]), round(float(dry[i]), 1), round(float(end[i]), 1), int(d[i, 3]), int(d[i, 5]))
+    ms = gpu.last_render_ms()
+    gpu.sync()
+    gpu.set_option(pkg.gpu.OPT_DEBUG_BUFFER, 0)
+    h = pkg.render.hits_to_numpy(hits)
+    steps_mean = float((h["info"] & 0xFF).mean())
+    hit_frac = float(((h["info"] >> 16) & 1).mean())
+    d = dbg.cpu().numpy().view(np.uint32)
+    d = d[d[:, 2] != 0].astype(np.int64)
+    t0 = d[:, 0].min()
+    start, dry, end = (d[:, 0] - t0) * 0.01, (d[:, 1] - t0) * 0.01, (d[:, 2] - t0) * 0.01  # us
+    pct = [0, 1, 5, 25, 50, 75, 95, 99, 100]
+    rounds = d[:, 3].sum()
+    life_cyc = d[:, 8] + d[:, 9] + d[:, 10]
+    out = {
+        "scene": a.scene, "w": W, "h": H, "words": int(words.size), "steps_mean": round(steps_mean, 2), "hit_frac": round(hit_frac, 4),
+        "kernel_us_plain_build": round(ms_plain * 1e3, 1), "kernel_us_timeline_build": round(ms * 1e3, 1), "waves": int(len(d)),
+        "pct": pct,
+        "start_us": np.percentile(start, pct).round(1).tolist(), "dry_us": np.percentile(dry, pct).round(1).tolist(),
+        "end_us": np.percentile(end, pct).round(1).tolist(), "drain_us": np.percentile(end - dry, pct).round(1).tolist(),
+        "rounds_per_wave": np.percentile(d[:, 3], pct).round(0).tolist(),
+        "us_per_round": np.percentile((end - start) / np.maximum(d[:, 3], 1), pct).round(2).tolist(),
+        "total_rounds": int(rounds), "active_lanes_per_round": round(float(d[:, 4].sum() / max(rounds, 1)), 2),
+        "refills_per_round": round(float(d[:, 6].sum() / max(rounds, 1)), 3), "strips_generated": int(d[:, 7].sum()),
+        # phase clocks: mean shader cycles per wave, and per round
+        "cycles_per_wave": {"refill_incl_gen": int(d[:, 8].mean()), "gen": int(d[:, 11].mean()), "descent": int(d[:, 9].mean()),
+                            "step": int(d[:, 10].mean()), "sum": int(life_cyc.mean())},
+        "cycles_per_round": {"refill_incl_gen": round(float(d[:, 8].sum() / max(rounds, 1)), 1), "gen": round(float(d[:, 11].sum() / max(rounds, 1)), 1),
+                             "descent": round(float(d[:, 9].sum() / max(rounds, 1)), 1), "step": round(float(d[:, 10].sum() / max(rounds, 1)), 1)},
+        "cycles_per_generated_strip": round(float(d[:, 11].sum() / max(d[:, 7].sum(), 1)), 1),
+        "shader_clock_ghz_in_kernel": round(float(np.median(life_cyc / np.maximum((d[:, 2] - d[:, 0]) * 10.0, 1))), 3),
+        # descent shape: wave-level iterations (dependent loads) per round vs the mean over lanes
+        "descent": {"wave_iters_per_round": round(float(d[:, 12].sum() / max(rounds, 1)), 2),
+                    "wave_iters_per_descending_round": round(float(d[:, 12].sum() / max(d[:, 14].sum(), 1)), 2),
+                    "lane_levels_per_descending_lane": round(float(d[:, 13].sum() / max(d[:, 15].sum(), 1)), 2),
+                    "lanes_in_loop_per_iter": round(float(d[:, 13].sum() / max(d[:, 12].sum(), 1)), 2),
+                    "descending_lanes_per_round": round(float(d[:, 15].sum() / max(rounds, 1)), 2),
+                    "cycles_per_wave_iter": round(float(d[:, 9].sum() / max(d[:, 12].sum(), 1)), 1)},
+        "last_ray_steps_by_end_decile": [int(np.median(d[np.argsort(end)][i * len(d) // 10:(i + 1) * len(d) // 10, 5])) for i in range(10)],
+    }
+    print(json.dumps(out, indent=1))
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump(out, f, indent=1)
+    gpu.close()
+
+
+if __name__ == "__main__":
+    main()
