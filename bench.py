@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--force-pipeline", action="store_true",
                     help="validation: run the N>1 code path (lanes, wire records, RCCL gather, assemble) with a one-rank "
                          "process group on a single GPU")
+    ap.add_argument("--opt", action="append", default=[], help="developer: NAME=VALUE for svo_set_option on every lane (e.g. PAIR_TABLE=0)")
     ap.add_argument("--cpu-frac", type=int, default=1, help="cpu_baseline traces the top 1/n of the frame's rows")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -147,6 +148,10 @@ def main():
         s_k = torch.cuda.Stream()
         gpu_k = pkg.Gpu(local_rank, stream=s_k.cuda_stream)
         lanes.append((gpu_k, pkg.Render.share_nodes(gpu_k, render), s_k))
+    for o in a.opt:
+        k, v = o.split("=")
+        for g, _, _ in lanes:
+            g.set_option(getattr(pkg.gpu, "OPT_" + k), int(v))
     gather_mode = None
     if pipelined and a.backend == "nccl":
         gather_mode = a.gather

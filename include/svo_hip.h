@@ -113,8 +113,13 @@ typedef enum svo_option {
                                    and more, where it measured faster.  The image is the same either way. */
     SVO_OPT_PAIR_TABLE = 13, /* STACK variant, static trees (pause_adaptive): descend two levels per dependent load through a
                                 device-built table that stores, for every node word, the 8 words of its children (8 x the node
-                                buffer in HBM, built on the first trace after the words changed).  1 (default) on, 0 off.
-                                Results do not depend on it. */
+                                buffer in HBM, built on the first trace after the words changed).  0 (default) off, 1 on: it
+                                halves the dependent loads but each one got slower, a net loss on the benchmark frame (DESIGN.md
+                                4.5).  Results do not depend on it. */
+    SVO_OPT_CULL = 14,       /* pixel frames, STACK variant: 64-pixel blocks whose rays all miss the cube (decided conservatively from
+                                the block's corner rays) get their all-zero records from a pre-pass and are never claimed by the
+                                trace.  0 off, 1 whenever the camera is outside the cube, 2 (default) when in addition the cube's
+                                projection leaves part of the screen empty.  Results do not depend on it. */
     SVO_OPT_PRIO_STEPS = 6   /* accepted and ignored: raising the issue priority of waves with old rays measured no effect and
                                 left the kernel */
 } svo_option;

@@ -71,6 +71,7 @@ void release_store(svo_ctx *ctx) {
     (void)hipSetDevice(st->device);
     if (st->nodes && st->owned) (void)hipFree(st->nodes);
     if (st->pairs) (void)hipFree(st->pairs);
+    if (st->pairs_ready) (void)hipEventDestroy(st->pairs_ready);
     if (st->last_write) (void)hipEventDestroy(st->last_write);
     delete st;
 }
@@ -89,6 +90,70 @@ int ensure_top_table(svo_ctx *ctx) {
     HIP_TRY(ctx, svo::launch_build_top_table(ctx->nodes, (uint32_t)ctx->capacity, ctx->top_table, ctx->stream));
     ctx->top_version = ctx->store->version;
     return SVO_OK;
+}
+
+// The pair table of the store (svo_ctx.h), built on first use after the words changed; *out stays nullptr when the table
+// is switched off, does not fit (address range or free memory) or the launch counts hits.
+int ensure_pairs(svo_ctx *ctx, const uint32_t **out) {
+    *out = nullptr;
+    svo_node_store *st = ctx->store;
+    if (!ctx->use_pairs || st->pairs_failed || st->capacity > svo::kPairsMaxWords) return SVO_OK;
+    if (st->pairs_version != st->version) {
+        const size_t bytes = (st->capacity + 1) * 8 * sizeof(uint32_t);
+        if (!st->pairs) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (size_t(1) << 30) ||
+                hipMalloc((void **)&st->pairs, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                st->pairs = nullptr;
+                st->pairs_failed = true;  // stay on the one-level walk: same results, more dependent loads
+                return SVO_OK;
+            }
+        }
+        int rc = order_after_last_write(ctx);
+        if (rc) return rc;
+        // (traces other contexts still have in flight read the old table: like the node words themselves, see svo_nodes_share)
+        HIP_TRY(ctx, svo::launch_build_pairs(st->nodes, (uint32_t)st->capacity, st->pairs, ctx->stream));
+        if (!st->pairs_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&st->pairs_ready, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(st->pairs_ready, ctx->stream));
+        st->pairs_builder = ctx->stream;
+        st->pairs_version = st->version;
+    } else if (st->pairs_builder != ctx->stream) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, st->pairs_ready, 0));
+    }
+    *out = st->pairs;
+    return SVO_OK;
+}
+
+// Is the pre-trace culling pass (strip_cull_kernel) worth its three small launches for this frame?  Only a heuristic -- which
+// strips are culled is decided on the device from camera_inverse alone.  Yes when the camera stands outside the cube and
+// the cube's projection (uniforms.camera, the forward matrix) leaves a good part of the screen empty.
+bool cull_worthwhile(const svo_ctx *ctx) {
+    if (ctx->cull_mode == 0) return false;
+    const float *ci = ctx->uniforms.camera_inverse, *cm = ctx->uniforms.camera;
+    const double w = ci[15];
+    if (!(fabs(w) > 1e-20)) return false;
+    const double o[3] = {ci[12] / w, ci[13] / w, ci[14] / w};  // camera_inverse * (0, 0, 0, 1)
+    if (!(fabs(o[0]) > 1.001 || fabs(o[1]) > 1.001 || fabs(o[2]) > 1.001)) return false;  // inside (or NaN): nothing to cull
+    if (ctx->cull_mode == 1) return true;
+    double lo[2] = {1e30, 1e30}, hi[2] = {-1e30, -1e30};
+    for (int v = 0; v < 8; v++) {
+        const double p[3] = {(v & 1) ? 1.0 : -1.0, (v & 2) ? 1.0 : -1.0, (v & 4) ? 1.0 : -1.0};
+        double c[4];
+        for (int r = 0; r < 4; r++) c[r] = cm[r] * p[0] + cm[4 + r] * p[1] + cm[8 + r] * p[2] + cm[12 + r];
+        if (!(c[3] > 1e-6)) return false;  // a corner of the cube at or behind the eye plane: the cube is all over the screen
+        for (int k = 0; k < 2; k++) {
+            const double ndc = c[k] / c[3];
+            lo[k] = ndc < lo[k] ? ndc : lo[k];
+            hi[k] = ndc > hi[k] ? ndc : hi[k];
+        }
+    }
+    double area = 1.0;
+    for (int k = 0; k < 2; k++) {
+        const double a0 = lo[k] < -1.0 ? -1.0 : lo[k], a1 = hi[k] > 1.0 ? 1.0 : hi[k];
+        area *= a1 > a0 ? (a1 - a0) / 2.0 : 0.0;
+    }
+    return area < 0.85;
 }
 
 struct TraceOpts {
@@ -136,10 +201,15 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     const bool debug_hits = (ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE) && (ctx->uniforms.flags & SVO_F_SHOW_HITS);
     const bool stack = want_stack && !debug_hits;
     a.shadow_hits = stack ? opt.shadow_out : nullptr;
+    if (stack && !counting) {
+        rc = ensure_pairs(ctx, &a.pairs);
+        if (rc) return rc;
+    }
     const uint32_t n_strips = (wd.n_items + 63u) / 64u;
     const bool schedule = ctx->schedule && n_strips <= svo::kMaxScheduledStrips;
     svo_ctx::Sched &sc = ctx->sched[opt.sched_slot & 1];
-    const bool filtered = stack && schedule && opt.skip != nullptr;
+    const bool cull = stack && schedule && wd.mode != 2 && hits != nullptr && cull_worthwhile(ctx);
+    const bool filtered = stack && schedule && (opt.skip != nullptr || cull);
     if (stack && schedule) {
         if (sc.cap < n_strips) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -159,11 +229,18 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         if (filtered) {
             // slots without a ray (secondary rays of pixels that hit nothing): this frame's lists leave out the strips
             // that consist of nothing else, ordered by the costs of an earlier frame when there are any
-            HIP_TRY(ctx, svo::launch_schedule_skipping(opt.skip, wd.n_items, sc.valid ? sc.cost : nullptr, sc.cls_now, sc.order, n_strips,
-                                                       a.order_cap, ctx->stream));
+            // (likewise for pixel frames seen from outside the cube: strips of sky are culled before the trace, their zero
+            // records written by the culling pass)
+            if (opt.skip)
+                HIP_TRY(ctx, svo::launch_schedule_skipping(opt.skip, wd.n_items, sc.valid ? sc.cost : nullptr, sc.cls_now, sc.order, n_strips,
+                                                           a.order_cap, ctx->stream));
+            else
+                HIP_TRY(ctx, svo::launch_schedule_culling(a, sc.valid ? sc.cost : nullptr, sc.cls_now, sc.order, n_strips, a.order_cap,
+                                                          ctx->stream));
             a.order = sc.order;
+            sc.order_filtered = true;  // these lists leave strips out: good for this frame only
         } else {
-            a.order = sc.valid ? sc.order : nullptr;
+            a.order = (sc.valid && !sc.order_filtered) ? sc.order : nullptr;
         }
     }
     svo::LaunchInfo li{};
@@ -209,12 +286,13 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         // frames is a backstop for node buffers written behind this context's back).
         const bool same_input = (wd.mode != 2 || opt.sched_slot == 1) && sc.built_nodes_version == ctx->store->version &&
                                 memcmp(&sc.built_uniforms, &ctx->uniforms, sizeof(svo_uniforms)) == 0 && sc.age < 64;
-        const bool rebuild = schedule && (!sc.valid || (!same_input && sc.age + 1 >= ctx->sched_period));
+        const bool rebuild = schedule && (!sc.valid || (sc.order_filtered && !filtered) || (!same_input && sc.age + 1 >= ctx->sched_period));
         // (a launch with a skip mask builds its lists before the trace, every frame: here only the costs are measured)
         HIP_TRY(ctx, svo::launch_post(a, li, rebuild ? sc.cost : nullptr, sc.order, n_strips, (n_strips + 7u) / 8u + 16u,
                                       rebuild && !filtered, ctx->stream));
         ctx->frame_parity ^= 1;
         if (rebuild) {
+            if (!filtered) sc.order_filtered = false;  // the post pass has just built complete lists
             sc.key = wd;
             sc.valid = true;
             sc.age = 0;
@@ -546,6 +624,10 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
         case SVO_OPT_TREE_DEPTH:
             if (value < 1 || value > 31) return fail(ctx, SVO_ERR_ARG, "tree depth must be 1..31");
             ctx->tree_depth = (uint32_t)value;  // (which kernel that means is decided per launch, see trace_launch)
+            return SVO_OK;
+        case SVO_OPT_CULL:
+            if (value < 0 || value > 2) return fail(ctx, SVO_ERR_ARG, "cull: 0 (off), 1 (whenever the camera is outside the cube) or 2 (automatic)");
+            ctx->cull_mode = (int)value;
             return SVO_OK;
         case SVO_OPT_PAIR_TABLE:
             if (value < 0 || value > 1) return fail(ctx, SVO_ERR_ARG, "pair table: 0 (off) or 1 (on)");

@@ -27,6 +27,8 @@ struct svo_node_store {
     uint32_t *pairs = nullptr;
     uint64_t pairs_version = 0;  // store version the table was built from (0: never)
     bool pairs_failed = false;   // allocation failed once: stay on the one-level descent
+    hipEvent_t pairs_ready = nullptr;   // recorded behind the build on the building context's stream
+    hipStream_t pairs_builder = nullptr;
 };
 
 struct svo_ctx {
@@ -40,7 +42,8 @@ struct svo_ctx {
     size_t capacity = 0;
     uint64_t top_version = 0;    // store version this context's top table was built from (0: none)
     uint32_t *top_table = nullptr;
-    int use_pairs = 1;           // SVO_OPT_PAIR_TABLE
+    int use_pairs = 0;           // SVO_OPT_PAIR_TABLE
+    int cull_mode = 2;           // SVO_OPT_CULL
     void *comm = nullptr;        // ncclComm_t (svo_comm.cpp); world size and rank of this context in it
     int comm_world = 0, comm_rank = 0;
     hipStream_t comm_stream = nullptr;  // the gathers run here, ordered against `stream` by the two events
@@ -76,6 +79,7 @@ struct svo_ctx {
         uint32_t *order = nullptr;
         size_t cap = 0;
         bool valid = false;
+        bool order_filtered = false;  // `order` was built for one frame without its empty / culled strips: not a general schedule
         uint32_t age = 0;
         svo::WorkDesc key{};
         // what the schedule was measured on: while camera and tree stay the same it stays exact and is not rebuilt

@@ -40,6 +40,7 @@ struct TraceArgs {
     const uint32_t *nodes;
     uint32_t n_words;
     const uint32_t *top_table;  // kTopEntries words (device) or nullptr
+    const uint32_t *pairs;      // STACK, optional: the pair table, 8 * (n_words + 1) words (two levels per load; static trees)
     svo_uniforms u;
     WorkDesc work;
     const float *rays;          // mode 2
@@ -72,6 +73,8 @@ struct LaunchInfo {
 
 hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint32_t *top_table,
                                   hipStream_t stream);
+hipError_t launch_build_pairs(const uint32_t *nodes, uint32_t n_words, uint32_t *pairs, hipStream_t stream);
+constexpr size_t kPairsMaxWords = (1u << 27) - 8u;  // byte offsets into the table must fit 32 bits
 hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream);
 int stack_max_depth(bool deep);
 // after a STACK trace: deferred rays, per-strip costs (cost != nullptr) and the next schedule; re-arms the counters
@@ -83,6 +86,10 @@ hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cos
 // explicit rays with a skip mask: this frame's strip lists without the strips that hold no ray (classes from `prev`, or screen order)
 hipError_t launch_schedule_skipping(const uint8_t *skip, uint32_t n_items, const uint8_t *prev, uint8_t *cls, uint32_t *sched,
                                     uint32_t n_strips, uint32_t cap, hipStream_t stream);
+// pixel frames seen from outside the cube: this frame's strip lists without the strips whose rays all miss it (their all-zero
+// records are written here); args carries the work layout, the uniforms and the output buffers of the trace that follows
+hipError_t launch_schedule_culling(const TraceArgs &args, const uint8_t *prev, uint8_t *cls, uint32_t *sched, uint32_t n_strips,
+                                   uint32_t cap, hipStream_t stream);
 // secondary rays of the hit pixels of args.hits; pixels without a hit get skip = 1 and a zero record in `out` instead of a ray
 // (rays k_first .. n_secondary - 1; slot of ray k of record r: (k - k_first) * n_records + r)
 hipError_t launch_secondary_gen(const TraceArgs &args, const float *aux_t, float *rays, uint8_t *skip, svo_hit *out, uint32_t k_first,

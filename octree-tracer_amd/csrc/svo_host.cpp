@@ -126,6 +126,26 @@ struct VoxFile {
     bool ok = false;
 };
 
+// MagicaVoxel's default palette (the table of the .vox format description), for files saved without an RGBA chunk --
+// dot_vox::load_bytes falls back to it and the reference loads such files (cpu_octree.rs:177-193).  Entry k of the
+// array is the colour of FILE index k + 1, the position an RGBA chunk would give it: a 6x6x6 colour cube (blue fastest,
+// steps of 0x33, black left out) followed by red, green, blue and grey ramps.  dot_vox's own copy of the table cannot be
+// compared here (crate source absent): the index convention is the file format's.
+void default_palette(uint32_t pal[256]) {
+    static const uint8_t ramp[10] = {0xee, 0xdd, 0xbb, 0xaa, 0x88, 0x77, 0x55, 0x44, 0x22, 0x11};
+    for (uint32_t j = 0; j < 215; j++) {
+        const uint32_t r = 0xff - 0x33 * (j / 36), g = 0xff - 0x33 * ((j / 6) % 6), b = 0xff - 0x33 * (j % 6);
+        pal[j] = 0xff000000u | (b << 16) | (g << 8) | r;
+    }
+    for (uint32_t k = 0; k < 10; k++) {
+        pal[215 + k] = 0xff000000u | ramp[k];
+        pal[225 + k] = 0xff000000u | (uint32_t(ramp[k]) << 8);
+        pal[235 + k] = 0xff000000u | (uint32_t(ramp[k]) << 16);
+        pal[245 + k] = 0xff000000u | (uint32_t(ramp[k]) << 16) | (uint32_t(ramp[k]) << 8) | ramp[k];
+    }
+    pal[255] = 0;
+}
+
 // Minimal MagicaVoxel reader: first SIZE/XYZI pair (model 0) and the RGBA chunk.  This is what
 // cpu_octree.rs:178-193 consumes from dot_vox 4.1.0 (i = file colour index - 1; palette words LE).
 bool parse_vox(const uint8_t *d, size_t len, VoxFile &v, std::string &why) {
@@ -151,7 +171,7 @@ bool parse_vox(const uint8_t *d, size_t len, VoxFile &v, std::string &why) {
         at += 12 + size_t(n) + kids;
     }
     if (!got_size || !got_xyzi) { why = "no model in .vox"; return false; }
-    if (!got_rgba) { why = "no RGBA chunk (MagicaVoxel default palette not supported)"; return false; }
+    if (!got_rgba) default_palette(v.palette);
     return v.ok = true;
 }
 

@@ -383,6 +383,45 @@ __global__ __launch_bounds__(256) void build_top_table_kernel(const uint32_t *no
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pair table: two octree levels per dependent load.  Row p (8 words) holds, for node word p, what a ray
+// finds one level further down: the 8 words of p's child group -- or, when p is a leaf, 8 copies of p itself with bit 0
+// set ("the walk ended one level early").  A descent step that knows the child group G of level a and the child choices
+// c1 (level a) and c2 (level a + 1) reads pairs[(G + c1) * 8 + c2] and is two levels further down, where the node array
+// needs word G + c1 first and then a second, dependent load.  Counter bits (the low four) are not copied: the table is
+// used while the tree is static (pause_adaptive) and rebuilt when the words change.  Row n_words stands for "a word past
+// the end of the buffer" (reads as 0: interior, child group 0), which keeps the walk identical to load_word's
+// out-of-range rule for malformed arrays.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kPairEarly = 1u;
+
+__global__ __launch_bounds__(256) void build_pairs_kernel(const uint32_t *nodes, uint32_t n_words, uint32_t *pairs) {
+    const rsrc_t rs = make_rsrc(nodes, n_words);
+    for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p <= n_words; p += gridDim.x * 256u) {
+        const uint32_t w = load_word(rs, p);  // p == n_words: out of range, 0
+        uint32_t v[8];
+        if ((w >> 4) >= kVoxelOffset) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = (w & ~15u) | kPairEarly;
+        } else {
+            const uint32_t q = w >> 4;
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = load_word(rs, q + (uint32_t)c) & ~15u;
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(pairs + 8ull * p);
+        dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+hipError_t launch_build_pairs(const uint32_t *nodes, uint32_t n_words, uint32_t *pairs, hipStream_t stream) {
+    (void)hipGetLastError();
+    uint32_t blocks = (n_words + 256u) / 256u;
+    if (blocks > 65536u) blocks = 65536u;
+    hipLaunchKernelGGL(build_pairs_kernel, dim3(blocks), dim3(256), 0, stream, nodes, n_words, pairs);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Variant STACK (see file header).
 // ---------------------------------------------------------------------------------------------
 // Path code of a position: bit (D - d) of the code is the child choice `pos > centre` (or `>=`)
@@ -508,13 +547,17 @@ constexpr int kPoolWords = 11;
 // a clean ray), so  A = (C - P) + H,  t = A / Dr,  G = (P + Dr * t) +- K  are exactly 2^23 times the
 // reference's  a,  the same t,  and  2^23 * voxel_pos  -- and G is what the path codes need.
 // CNT: hit counters live (adaptive mode, shader.wgsl:157-161), see step 3a in the loop.
-template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD>
+// PAIRS: descend through the pair table, two levels per load (static trees; never together with CNT, which needs the
+// address of every word on the path).
+template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD, bool PAIRS>
 __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
     constexpr int SMAX = K + 1 + NS;   // last level kept on the LDS stack = deepest level resolved
     static_assert(SMAX <= D - 1, "stack deeper than the path codes");
+    static_assert(!(PAIRS && CNT), "the counting instantiation walks every word");
+    constexpr uint32_t kTag = 0x80000000u;  // PAIRS: stack entry = child group of the level ABOVE the row's level
     constexpr int TBL = 1 << (3 * K);
     constexpr float kScale = 8388608.0f;  // 2^23
     constexpr float kInvScale = 1.0f / 8388608.0f;
@@ -541,6 +584,8 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
     const uint32_t lane = tid & 63u;
     uint32_t *pool = pool_all + (tid >> 6) * (kPoolWords * 64);
     const rsrc_t rs = make_rsrc(a.nodes, a.n_words);
+    // the pair table: (n_words + 1) rows of 32 bytes (the host keeps n_words + 1 below 2^27, so byte offsets fit 32 bits)
+    const rsrc_t rp = PAIRS ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.pairs), 0, (int)((a.n_words + 1u) << 5), 0x00020000) : rs;
 
     for (uint32_t i = tid; i < (uint32_t)TBL; i += BLOCK) tbl[i] = a.top_table[i];
     if (CNT && tid < (uint32_t)kTopAuxEntries) aux[tid] = a.top_table[(uint32_t)TBL + tid];
@@ -639,7 +684,8 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
             addr = top ? cell : addr;
         }
         const uint32_t e = lds[addr];
-        lvl = top ? (e >> 27) : r;
+        // PAIRS: a tagged stack entry is the child group of level r - 1 (the walk went through level r without stopping)
+        lvl = top ? (e >> 27) : (PAIRS ? r - (e >> 31) : r);
         nidx = e & 0x07FFFFFFu;
     };
 
@@ -652,7 +698,14 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
         uint32_t ncode = ((nm & 1u) ? c0n : 0u) | ((nm & 2u) ? (c1n << 2) : 0u) | ((nm & 4u) ? (c2n << 4) : 0u);
         if (st & ST_ENTRY) ncode = out >> 26;             // no step taken: the entry normal
         if (!stop_here && !inb) ncode = 0u;               // left the cube: the miss record carries no normal
-        const uint32_t value = too_deep ? 0xFF000000u : (solid ? (leaf_off >> 2) : (!inb ? 0x20202000u : 0xFF000000u));
+        uint32_t leaf_index = leaf_off >> 2;
+        if (PAIRS && solid && (leaf_off & 1u)) {
+            // the leaf was found one level below word leaf_off >> 2, whose pointer the walk never read: read it now
+            const uint32_t bit = (uint32_t)D - L;
+            leaf_index = (load_word(rs, leaf_off >> 2) >> 4) +
+                         ((((uint32_t)ix >> bit) & 1u) << 2 | (((uint32_t)iy >> bit) & 1u) << 1 | (((uint32_t)iz >> bit) & 1u));
+        }
+        const uint32_t value = too_deep ? 0xFF000000u : (solid ? leaf_index : (!inb ? 0x20202000u : 0xFF000000u));
         const uint32_t depth = (too_deep || (!solid && inb)) ? 100u : L;
         const uint32_t hit = (stop_here || inb) ? 1u : 0u;
         const bool was_shadow = SHD && (st & ST_SHADOW) != 0u;
@@ -712,7 +765,113 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
 
     for (;;) {
         if (DBG) c_mark = __builtin_amdgcn_s_memtime();
-        // ---- 1. refill idle lanes from the ray pool (ballot compaction) ----
+        if (DBG) {  // per-wave timeline build only (SVO_OPT_DEBUG_BUFFER): the default instantiation carries none of this
+            n_rounds += 1;
+            const uint32_t nd = (uint32_t)__popcll(__ballot(st >= (ST_ACTIVE | ST_DESC)));
+            dbg_desc_start += nd;
+            dbg_desc_rounds += nd ? 1u : 0u;
+        }
+        // ---- 1. descent: one dependent word per level below the restart level (PAIRS: per two levels) ----
+        if (PAIRS && st >= (ST_ACTIVE | ST_DESC)) {
+            uint32_t sh = (uint32_t)D - lvl + 1u;  // (bit of the path codes that selects the child of level lvl) + 1
+            // stack row of level lvl + 1 (rows: levels SBASE .. SMAX + 1; a walk that starts above level K + 1 dumps into row 0)
+            uint32_t row = max(lvl, (uint32_t)(SBASE - 1)) - (uint32_t)(SBASE - 1);
+            uint32_t w, p1;
+            int32_t key;
+            do {
+                if (DBG) {
+                    const uint64_t in_loop = __ballot(true);
+                    if (lane == (uint32_t)__ffsll((unsigned long long)in_loop) - 1u) {
+                        dbg_desc_iters += 1u;
+                        dbg_desc_lanes += (uint32_t)__popcll(in_loop);
+                    }
+                }
+                // levels a = D - (sh - 1) and a + 1: child choices c1, c2 from the path codes
+                uint32_t c1, c2, t1, t2;
+                asm("v_add_u32 %4, -1, %4\n\t"
+                    "v_bfe_u32 %0, %5, %4, 1\n\t"
+                    "v_bfe_u32 %2, %6, %4, 1\n\t"
+                    "v_lshl_or_b32 %0, %0, 1, %2\n\t"
+                    "v_bfe_u32 %2, %7, %4, 1\n\t"
+                    "v_lshl_or_b32 %0, %0, 1, %2\n\t"
+                    "v_add_u32 %4, -1, %4\n\t"
+                    "v_bfe_u32 %1, %5, %4, 1\n\t"
+                    "v_bfe_u32 %3, %6, %4, 1\n\t"
+                    "v_lshl_or_b32 %1, %1, 1, %3\n\t"
+                    "v_bfe_u32 %3, %7, %4, 1\n\t"
+                    "v_lshl_or_b32 %1, %1, 1, %3"
+                    : "=&v"(c1), "=&v"(c2), "=&v"(t1), "=&v"(t2), "+v"(sh)
+                    : "v"(ix), "v"(iy), "v"(iz));
+                p1 = min(nidx + c1, a.n_words);  // a pointer past the buffer reads the zero row, like load_word
+                w = __builtin_amdgcn_raw_buffer_load_b32(rp, (int)((p1 << 5) + (c2 << 2)), 0, 0);
+                lds[(uint32_t)TBL + min(row, (uint32_t)NS) * BLOCK + tid] = nidx | kTag;       // level a + 1: "come from level a"
+                lds[(uint32_t)TBL + min(row + 1u, (uint32_t)NS) * BLOCK + tid] = w >> 4;      // level a + 2
+                row += 2u;
+                nidx = w >> 4;
+                // done: the walk ended early (bit 0), or the word of level a + 1 is a leaf (bit 31), or level a + 1 >= SMAX
+                key = (int32_t)(w | (w << 31) | (sh - (uint32_t)(D - SMAX + 1)));
+            } while (key >= 0);
+            const bool early = (w & kPairEarly) != 0u;
+            uint32_t lb = (uint32_t)D - sh;                    // level a + 1
+            uint32_t lw = w & ~kPairEarly;
+            if (!early && lb > (uint32_t)SMAX) lw = 0u;       // level SMAX itself is interior: deeper than this kernel resolves
+            lvl = early ? lb - 1u : min(lb, (uint32_t)SMAX);
+            leaf_off = (p1 << 2) | (early ? 0u : 1u);         // bit 0: the leaf is a child of that word (flush_record)
+            leaf_w = lw;
+            st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
+        }
+        if (!PAIRS && st >= (ST_ACTIVE | ST_DESC)) {  // DESC implies ACTIVE: one unsigned compare
+            uint32_t off, w, key;
+            uint32_t sh = (uint32_t)D - lvl + 1u;            // (bit of the path codes that selects the child) + 1
+            // slot of level lvl + 1; a descent that starts on a leaf above level K+1 (from the top table) pushes its
+            // one dead word into row 0, which is rewritten before any restart can read it
+            uint32_t sp = (uint32_t)TBL + (max(lvl, (uint32_t)(SBASE - 1)) - (uint32_t)(SBASE - 1)) * BLOCK + tid;
+            // straight-line body, one exit test: the push also happens on the exiting iteration (it lands in the
+            // slot below the leaf, which no restart reads; the stack has one spare row for an exit at level SMAX)
+            do {
+                if (DBG) {
+                    const uint64_t in_loop = __ballot(true);
+                    if (lane == (uint32_t)__ffsll((unsigned long long)in_loop) - 1u) {  // (tallies summed over lanes at the end)
+                        dbg_desc_iters += 1u;
+                        dbg_desc_lanes += (uint32_t)__popcll(in_loop);
+                    }
+                }
+                // sh -= 1 (level being read: D - sh); child = x << 2 | y << 1 | z; byte offset = (nidx + child) << 2.
+                // Three-operand forms the compiler does not pick by itself, in ONE asm statement (the compiler pads every
+                // inline-asm statement with an s_nop, and keeping the decrement inside saves a copy of the counter)
+                uint32_t tmp;
+                asm("v_add_u32 %2, -1, %2\n\t"
+                    "v_bfe_u32 %0, %3, %2, 1\n\t"
+                    "v_bfe_u32 %1, %4, %2, 1\n\t"
+                    "v_lshl_or_b32 %0, %0, 1, %1\n\t"
+                    "v_bfe_u32 %1, %5, %2, 1\n\t"
+                    "v_lshl_or_b32 %0, %0, 1, %1\n\t"
+                    "v_add_lshl_u32 %0, %6, %0, 2"
+                    : "=&v"(off), "=&v"(tmp), "+v"(sh)
+                    : "v"(ix), "v"(iy), "v"(iz), "v"(nidx));
+                w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
+                nidx = w >> 4;
+                lds[sp] = nidx;
+                sp += BLOCK;
+                // sign bit: a leaf (word >= VOXEL_OFFSET << 4), or level SMAX reached (deeper trees are refused)
+                key = w | (sh - (uint32_t)(D - SMAX + 1));
+            } while ((int32_t)key >= 0);
+            lvl = (uint32_t)D - sh;
+            leaf_off = off;
+            leaf_w = w;
+            st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
+        }
+
+        if (DBG) {
+            const uint64_t now = __builtin_amdgcn_s_memtime();
+            c_desc += (uint32_t)(now - c_mark);
+            c_mark = now;
+        }
+        // ---- 2. refill idle lanes from the ray pool (ballot compaction) ----
+        // (Between the descent and the step: the stores and atomics issued here -- records of finished rays, records of
+        // rays that miss the cube, the next claim -- are counted in vmcnt together with the loads, in order, so a descent
+        // right behind them would wait for their acknowledgements; the step's arithmetic runs meanwhile.  Rays picked up
+        // here descend in the next round.)
         // Common case first and cheap: fewer than refill_min idle lanes -> straight on.  (refill_min <= 64, so a wave
         // without active lanes always takes the slow path, where the exit test lives.)
         uint64_t act = __ballot((int32_t)st < 0);  // ST_ACTIVE is the sign bit: one compare
@@ -864,67 +1023,14 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
             if (act == 0ull && pool_n == 0u && next == 0xFFFFFFFFu) break;
         }
 
-        if (DBG) {  // per-wave timeline build only (SVO_OPT_DEBUG_BUFFER): the default instantiation carries none of this
-            n_rounds += 1;
-            dbg_active += (uint32_t)__popcll(__ballot((st & ST_ACTIVE) != 0u));
+        if (DBG) {
+            dbg_active += (uint32_t)__popcll(__ballot((st ^ ST_DESC) >= (ST_ACTIVE | ST_DESC)));
             const uint64_t now = __builtin_amdgcn_s_memtime();
             c_refill += (uint32_t)(now - c_mark);
             c_mark = now;
-            const uint32_t nd = (uint32_t)__popcll(__ballot(st >= (ST_ACTIVE | ST_DESC)));
-            dbg_desc_start += nd;
-            dbg_desc_rounds += nd ? 1u : 0u;
-        }
-
-        // ---- 2. descent: one dependent word per level below the restart level ----
-        if (st >= (ST_ACTIVE | ST_DESC)) {  // DESC implies ACTIVE: one unsigned compare
-            uint32_t off, w, key;
-            uint32_t sh = (uint32_t)D - lvl + 1u;            // (bit of the path codes that selects the child) + 1
-            // slot of level lvl + 1; a descent that starts on a leaf above level K+1 (from the top table) pushes its
-            // one dead word into row 0, which is rewritten before any restart can read it
-            uint32_t sp = (uint32_t)TBL + (max(lvl, (uint32_t)(SBASE - 1)) - (uint32_t)(SBASE - 1)) * BLOCK + tid;
-            // straight-line body, one exit test: the push also happens on the exiting iteration (it lands in the
-            // slot below the leaf, which no restart reads; the stack has one spare row for an exit at level SMAX)
-            do {
-                if (DBG) {
-                    const uint64_t in_loop = __ballot(true);
-                    if (lane == (uint32_t)__ffsll((unsigned long long)in_loop) - 1u) {  // (tallies summed over lanes at the end)
-                        dbg_desc_iters += 1u;
-                        dbg_desc_lanes += (uint32_t)__popcll(in_loop);
-                    }
-                }
-                // sh -= 1 (level being read: D - sh); child = x << 2 | y << 1 | z; byte offset = (nidx + child) << 2.
-                // Three-operand forms the compiler does not pick by itself, in ONE asm statement (the compiler pads every
-                // inline-asm statement with an s_nop, and keeping the decrement inside saves a copy of the counter)
-                uint32_t tmp;
-                asm("v_add_u32 %2, -1, %2\n\t"
-                    "v_bfe_u32 %0, %3, %2, 1\n\t"
-                    "v_bfe_u32 %1, %4, %2, 1\n\t"
-                    "v_lshl_or_b32 %0, %0, 1, %1\n\t"
-                    "v_bfe_u32 %1, %5, %2, 1\n\t"
-                    "v_lshl_or_b32 %0, %0, 1, %1\n\t"
-                    "v_add_lshl_u32 %0, %6, %0, 2"
-                    : "=&v"(off), "=&v"(tmp), "+v"(sh)
-                    : "v"(ix), "v"(iy), "v"(iz), "v"(nidx));
-                w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
-                nidx = w >> 4;
-                lds[sp] = nidx;
-                sp += BLOCK;
-                // sign bit: a leaf (word >= VOXEL_OFFSET << 4), or level SMAX reached (deeper trees are refused)
-                key = w | (sh - (uint32_t)(D - SMAX + 1));
-            } while ((int32_t)key >= 0);
-            lvl = (uint32_t)D - sh;
-            leaf_off = off;
-            leaf_w = w;
-            st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
-        }
-
-        if (DBG) {
-            const uint64_t now = __builtin_amdgcn_s_memtime();
-            c_desc += (uint32_t)(now - c_mark);
-            c_mark = now;
         }
         // ---- 3. hit test / DDA step (shader.wgsl:215-244), clean rays, grid units ----
-        if ((int32_t)st < 0) {  // ST_ACTIVE
+        if ((st ^ ST_DESC) >= (ST_ACTIVE | ST_DESC)) {  // ST_ACTIVE and not ST_DESC: at a leaf (rays picked up above descend first)
             const uint32_t L = (st >> ST_L_SHIFT) & 31u;
             if (CNT) {
                 // ---- 3a. hit counters.  The reference's find_voxel bumps every word from the root to the leaf, once per
@@ -982,16 +1088,20 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                              (__builtin_fminf(__builtin_fminf(G0, G1), G2) >= -kScale);
             const bool stop_here = too_deep || solid;         // finish before stepping
             const uint32_t mbits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u);
-            if (!stop_here) {
-                // the step is taken (its normal, distance and -- if it stays inside -- count are what the record shows)
-                tcur = tnew;
-                st = ((st & ~(ST_M_MASK | ST_ENTRY)) | (mbits << ST_M_SHIFT)) + (inb ? 1u : 0u);
-            }
-            if (stop_here || !inb || (st & 0xFFu) > 100u) {
+            // One branch for the common case -- an empty leaf, the step stays inside the cube and below the step cap (the
+            // count after this step exceeds 100 iff it is 100 now) -- and one for everything that ends the ray.
+            if (stop_here || !inb || (st & 0xFFu) >= 100u) {
+                if (!stop_here) {
+                    // the step is taken (its normal, distance and -- if it stays inside -- count are what the record shows)
+                    tcur = tnew;
+                    st = ((st & ~(ST_M_MASK | ST_ENTRY)) | (mbits << ST_M_SHIFT)) + (inb ? 1u : 0u);
+                }
                 if (too_deep) atomicOr(a.status, 1u);
                 st = (st & ~(ST_ACTIVE | ST_DESC)) | ST_PENDING | (too_deep ? ST_F_TOODEEP : 0u) |
                      (solid ? ST_F_SOLID : 0u) | (inb ? ST_F_INB : 0u);
             } else {
+                tcur = tnew;
+                st = ((st & ~(ST_M_MASK | ST_ENTRY)) | (mbits << ST_M_SHIFT)) + 1u;
                 // new path codes: the position is inside the cube, so no clamping of G
                 int32_t jx, jy, jz;
                 if (GE) {
@@ -1495,15 +1605,20 @@ template <bool GE, int NS>
 static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
     const uint32_t strip_items = args.order ? 64u : (li.strip_items ? li.strip_items : 64u);
     const bool shd = args.shadow_hits != nullptr;  // fused shadow rays (no timeline build of that one)
-    auto kern = shd ? (args.count_nodes ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, true>
-                                        : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, true>)
-                    : (args.count_nodes ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, false>
-                                        : (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false>
-                                                      : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false>));
+    const bool pairs = args.pairs != nullptr && !args.count_nodes;  // two levels per load (static trees)
+    auto kern = shd ? (args.count_nodes ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, true, false>
+                                        : (pairs ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, true, true>
+                                                 : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, true, false>))
+                    : (args.count_nodes
+                           ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, false, false>
+                           : (args.debug ? (pairs ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false, true>
+                                                  : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false, false>)
+                                         : (pairs ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false, true>
+                                                  : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false, false>)));
     size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
                                 (args.count_nodes ? kTopAuxEntries : 0)) * sizeof(uint32_t);
     // cached per context (= per device): [deep stack?][fused shadows?][counting instantiation?]
-    int &blocks_per_cu = li.occupancy[(NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
+    int &blocks_per_cu = li.occupancy[(pairs ? 8 : 0) + (NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
     if (blocks_per_cu == 0) {
         int n = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kStackBlock, lds_bytes);
@@ -1567,6 +1682,91 @@ __global__ __launch_bounds__(256) void strip_classes_kernel(const uint8_t *skip,
         for (uint32_t q = s * 64u; q < n_items; q++) empty = empty && skip[q] != 0u;
     }
     cls[s] = empty ? (uint8_t)0xFFu : (prev ? prev[s] : (uint8_t)0u);
+}
+
+// Strips whose rays all miss the cube (sky): decided per 64-pixel block from the four corner rays, before the trace, so
+// that such strips are never claimed, generated or refilled from -- on frames that are mostly sky that is most of the
+// per-strip work.  The rays of a block are pos + s * (point(pixel) - pos), s > 0, where point() is the
+// projective image of the pixel under camera_inverse: the block's points lie in the planar convex quadrilateral Q of its
+// four corner pixels (same sign of w at the corners), so every ray lies in the cone over Q with apex pos.  If one side
+// plane of that cone (through pos and an edge of Q, normal n pointing into the cone) has the whole cube strictly on its
+// outer side -- max over the cube's corners of n.(v - pos) = |n.x| + |n.y| + |n.z| - n.pos < -margin -- no ray of the block
+// meets the cube and ray_box_dist returns 0 for each of them (shader.wgsl:66-80: v7 > v8).  The margin (1e-3 of the
+// plane function's scale, ~1e-3 rad) is four orders of magnitude above the rounding of either computation: blocks
+// anywhere near the cube's silhouette are NOT culled and take the ordinary path.  A culled strip's 64 records are what
+// the trace writes for rays that never enter the cube: all zeros.
+__global__ __launch_bounds__(256) void strip_cull_kernel(TraceArgs a, const uint8_t *prev, uint8_t *cls, uint32_t n_strips) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = gridDim.x * 4u;
+    float p4[4];
+    mat_vec(a.u.camera_inverse, 0.0f, 0.0f, 0.0f, 1.0f, p4);
+    const float o0 = p4[0] / p4[3], o1 = p4[1] / p4[3], o2 = p4[2] / p4[3];
+    for (uint32_t s = wave; s < n_strips; s += n_waves) {
+        const ItemFast it = decode_item_fast(a.work, s * 64u + lane);
+        // pixel bounds of the strip's valid pixels
+        uint32_t x_lo = it.valid ? it.px : 0xFFFFFFFFu, x_hi = it.valid ? it.px : 0u, y_lo = it.valid ? it.py : 0xFFFFFFFFu, y_hi = it.valid ? it.py : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            x_lo = min(x_lo, (uint32_t)__shfl_xor((int)x_lo, o));
+            x_hi = max(x_hi, (uint32_t)__shfl_xor((int)x_hi, o));
+            y_lo = min(y_lo, (uint32_t)__shfl_xor((int)y_lo, o));
+            y_hi = max(y_hi, (uint32_t)__shfl_xor((int)y_hi, o));
+        }
+        bool culled = false;
+        if (x_lo <= x_hi) {  // (a strip of padding only has no pixel: nothing to trace, nothing to write)
+            // corner k of the quadrilateral, in order around it: (lo,lo) (hi,lo) (hi,hi) (lo,hi)
+            float q[4][3];
+            bool ok = true;
+            float wsign = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t px = (k == 1 || k == 2) ? x_hi : x_lo, py = (k >= 2) ? y_hi : y_lo;
+                const float cx = ((float)px + 0.5f) / a.u.dimensions[0] * 2.0f - 1.0f;
+                const float cy = -(((float)py + 0.5f) / a.u.dimensions[1] * 2.0f - 1.0f);
+                float d4[4];
+                mat_vec(a.u.camera_inverse, cx, cy, 1.0f, 1.0f, d4);
+                q[k][0] = d4[0] / d4[3] - o0; q[k][1] = d4[1] / d4[3] - o1; q[k][2] = d4[2] / d4[3] - o2;
+                ok = ok && fabsf(d4[3]) > 1.0e-20f && (k == 0 || (d4[3] > 0.0f) == (wsign > 0.0f));
+                wsign = d4[3];
+            }
+            ok = ok && fabsf(p4[3]) > 1.0e-20f;
+            if (ok) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float *u = q[k], *v = q[(k + 1) & 3], *w = q[(k + 2) & 3];
+                    float n0 = u[1] * v[2] - u[2] * v[1], n1 = u[2] * v[0] - u[0] * v[2], n2 = u[0] * v[1] - u[1] * v[0];
+                    const float inside = n0 * w[0] + n1 * w[1] + n2 * w[2];  // the opposite corner is inside the cone
+                    if (inside < 0.0f) { n0 = -n0; n1 = -n1; n2 = -n2; }
+                    const float reach = fabsf(n0) + fabsf(n1) + fabsf(n2);
+                    const float at_pos = n0 * o0 + n1 * o1 + n2 * o2;
+                    const float scale = reach + fabsf(n0 * o0) + fabsf(n1 * o1) + fabsf(n2 * o2);
+                    // a degenerate quadrilateral (inside == 0: a one-pixel-wide strip) or NaNs leave every comparison false
+                    if (fabsf(inside) > 0.0f && reach - at_pos < -1.0e-3f * scale) culled = true;
+                }
+            }
+        }
+        culled = __builtin_amdgcn_readfirstlane(culled ? 1u : 0u) != 0u;  // (wave-uniform by construction)
+        if (culled && it.valid) {
+            reinterpret_cast<uint4 *>(a.hits)[it.out] = make_uint4(0u, 0u, 0u, 0u);
+            if (a.aux_t) a.aux_t[it.out] = 0.0f;
+            if (a.shadow_hits) reinterpret_cast<uint4 *>(a.shadow_hits)[it.out] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (lane == 0) cls[s] = culled ? (uint8_t)0xFFu : (prev ? prev[s] : (uint8_t)0u);
+    }
+}
+
+// This frame's strip lists without the culled strips (classes from `prev`, or screen order); see launch_schedule_skipping.
+hipError_t launch_schedule_culling(const TraceArgs &args, const uint8_t *prev, uint8_t *cls, uint32_t *sched, uint32_t n_strips,
+                                   uint32_t cap, hipStream_t stream) {
+    (void)hipGetLastError();
+    uint32_t blocks = (n_strips + 3u) / 4u;
+    if (blocks > 8192u) blocks = 8192u;
+    hipLaunchKernelGGL(strip_cull_kernel, dim3(blocks), dim3(256), 0, stream, args, prev, cls, n_strips);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(cls + ((n_strips + 15u) & ~15u));
+    hipLaunchKernelGGL(strip_hist_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, (const uint8_t *)cls, n_strips, hist);
+    hipLaunchKernelGGL(strip_order_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, (const uint8_t *)cls,
+                       (const uint32_t *)hist, sched, n_strips, cap);
+    return hipGetLastError();
 }
 
 hipError_t launch_schedule_skipping(const uint8_t *skip, uint32_t n_items, const uint8_t *prev, uint8_t *cls, uint32_t *sched,

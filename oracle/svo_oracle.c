@@ -189,7 +189,21 @@ int64_t oracle_vox_parse(const uint8_t *data, size_t len, uint32_t size[3], uint
         off += 12 + (size_t)csize + (size_t)chsize;
     }
     if (!have_size || !have_xyzi) { set_err(err, errlen, "no model in .vox"); return -1; }
-    if (!have_rgba) { set_err(err, errlen, "no RGBA chunk (default palette not restated)"); return -1; }
+    if (!have_rgba && palette256) {
+        /* dot_vox falls back to MagicaVoxel's default palette (cpu_octree.rs:177-193 loads such files).  The table of the
+         * .vox format description, entry k = colour of file index k + 1: indices 1..215 a 6x6x6 cube (0xAABBGGRR, blue
+         * fastest, steps of 0x33, without black), then four ramps of ten.  dot_vox's copy is unavailable: unpinned. */
+        static const unsigned ramp[10] = {0xee, 0xdd, 0xbb, 0xaa, 0x88, 0x77, 0x55, 0x44, 0x22, 0x11};
+        int idx = 1;
+        for (int r = 5; r >= 0; r--)
+            for (int g = 5; g >= 0; g--)
+                for (int b = 5; b >= 0; b--)
+                    if (r || g || b) palette256[idx++ - 1] = 0xff000000u | ((uint32_t)(b * 0x33) << 16) | ((uint32_t)(g * 0x33) << 8) | (uint32_t)(r * 0x33);
+        for (int c = 0; c < 4; c++)
+            for (int k = 0; k < 10; k++, idx++)
+                palette256[idx - 1] = 0xff000000u | (c == 3 ? ramp[k] * 0x010101u : (uint32_t)ramp[k] << (8 * c));
+        palette256[255] = 0;
+    }
     return n_vox;
 }
 

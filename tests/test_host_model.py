@@ -190,3 +190,24 @@ def test_host_find_voxel_matches_oracle_descent(pkg, O, monu9_words):
         idx, depth, pos = o.find_voxel(p.tolist())
         v, vpos, d = O.find_voxel(monu9_words, p.tolist(), misc_bool=True)
         assert (idx, depth, pos) == (v, d, vpos)
+
+
+def test_vox_without_rgba_chunk_uses_the_default_palette(pkg, O):
+    """dot_vox falls back to MagicaVoxel's default palette for files saved without an RGBA chunk and the
+    reference loads them (cpu_octree.rs:177-193).  Product and oracle (independent codings of the format's table) agree,
+    and known entries come out: file index 1 = white, 216 = the first step of the red ramp, 255 = grey 0x11."""
+    import struct
+    size = 4
+    xyzi = np.array([[0, 0, 0, 1], [1, 0, 0, 216], [2, 0, 0, 255], [3, 3, 3, 37]], dtype=np.uint8)
+    blob = pkg.cpu_octree.vox_write(size, xyzi, np.arange(256, dtype=np.uint32))
+    at = blob.index(b"RGBA")
+    n = struct.unpack_from("<I", blob, at + 4)[0]
+    cut = blob[:at] + blob[at + 12 + n:]
+    cut = cut[:16] + struct.pack("<I", struct.unpack_from("<I", cut, 16)[0] - (12 + n)) + cut[20:]  # MAIN's children size
+    ours = pkg.CpuOctree.load_vox(cut).to_octree_words()
+    theirs = O.Tree.from_vox(cut).to_octree()
+    assert np.array_equal(ours, theirs)
+    leaves = sorted(int(w >> 4) - (1 << 27) for w in ours if (w >> 4) > (1 << 27))
+    # colour value = R << 16 | G << 8 | B (cpu_octree.rs:204 via Voxel::to_value)
+    j = 36  # file index 37 -> cube entry j = 36: R = 0xff - 0x33, G = B = 0xff
+    assert leaves == sorted([0xFFFFFF, 0xEE0000, 0x111111, (0xFF - 0x33) << 16 | 0xFF << 8 | 0xFF])

@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--prio", default="0")
     ap.add_argument("--schedule", default="8")
     ap.add_argument("--block", default="3")
+    ap.add_argument("--pairs", default="0")
+    ap.add_argument("--cull", default="2")
+    ap.add_argument("--pose", type=int, default=0)
     ap.add_argument("--motion", type=float, default=0.0, help="degrees of yaw added to the camera every frame")
     a = ap.parse_args()
     pkg = entry.load_package()
@@ -42,6 +45,13 @@ def main():
         z = np.load(os.path.join(ROOT, "tests/golden/monu9_vox.npz"))
         words = pkg.CpuOctree.from_voxels(int(z["size"][0]), z["xyzi"], z["palette"]).to_octree_words()
         cam, look = (0.1, 0.2, -1.5), (0.0, 0.0, 1.5)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import config_scenes as cs
+        if a.scene.startswith("config3"):
+            words, poses, _ = cs.config3(pkg)
+            cam, look = poses[1 if a.scene == "config3b" else 0]
+        else:
+            cam, look = cs.config2(pkg)[1][a.pose]
     print(f"scene {a.scene}: {words.size} words ({words.size * 4 / 1e6:.1f} MB) built in {time.time() - t0:.1f}s", flush=True)
     gpu = pkg.Gpu(0)
     render = pkg.Render(gpu, (a.w, a.h), words, capacity=words.size)
@@ -51,8 +61,8 @@ def main():
     hits = render.alloc_hits(a.w * a.h)
     n = a.w * a.h
     ref = None
-    for blockw, variant, refill, strip, dyn, grid, prio, sched in itertools.product(
-            [int(x) for x in a.block.split(",")],
+    for cull, pairs, blockw, variant, refill, strip, dyn, grid, prio, sched in itertools.product(
+            [int(x) for x in a.cull.split(",")], [int(x) for x in a.pairs.split(",")], [int(x) for x in a.block.split(",")],
             [int(x) for x in a.variants.split(",")], [int(x) for x in a.refill.split(",")],
             [int(x) for x in a.strip.split(",")], [int(x) for x in a.dynamic.split(",")],
             [int(x) for x in a.grid.split(",")], [int(x) for x in a.prio.split(",")],
@@ -67,6 +77,8 @@ def main():
         gpu.set_option(pkg.gpu.OPT_PRIO_STEPS, prio)
         gpu.set_option(pkg.gpu.OPT_SCHEDULE, sched)
         gpu.set_option(pkg.gpu.OPT_BLOCK_SHAPE, blockw)
+        gpu.set_option(pkg.gpu.OPT_PAIR_TABLE, pairs)
+        gpu.set_option(pkg.gpu.OPT_CULL, cull)
         ms = []
         for i in range(a.reps + 2):
             if a.motion:
@@ -86,7 +98,7 @@ def main():
             ref = h.copy()
         same = bool(np.array_equal(ref, h)) if not a.motion else None
         med = float(np.median(ms))
-        print(json.dumps({"variant": variant, "refill": refill, "strip": strip, "dynamic": dyn, "grid": grid, "prio": prio, "schedule": sched, "block": blockw,
+        print(json.dumps({"cull": cull, "pairs": pairs, "variant": variant, "refill": refill, "strip": strip, "dynamic": dyn, "grid": grid, "prio": prio, "schedule": sched, "block": blockw,
                           "ms_med": round(med, 4), "ms_min": round(min(ms), 4), "mrays_s": round(n / med / 1e3, 1),
                           "sig": sig, "same_as_first": same}), flush=True)
     steps = (ref[:, 2] & 0xFF)
