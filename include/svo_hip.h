@@ -120,10 +120,15 @@ typedef enum svo_option {
                                 the block's corner rays) get their all-zero records from a pre-pass and are never claimed by the
                                 trace.  0 off, 1 whenever the camera is outside the cube, 2 (default) when in addition the cube's
                                 projection leaves part of the screen empty.  Results do not depend on it. */
+    SVO_OPT_CAMERA_SHORTCUT = 15, /* pixel frames, camera inside the cube, STACK variant: every primary ray starts in the camera's leaf, so a wave
+                                walks from the root to it once and its lanes copy that walk when they pick up a ray.  1 (default) on, 0 off.
+                                Results do not depend on it. */
     SVO_OPT_PRIO_STEPS = 6   /* accepted and ignored: raising the issue priority of waves with old rays measured no effect and
                                 left the kernel */
 } svo_option;
 
+/* Number of HIP devices visible to the process (0 without a GPU). */
+int svo_device_count(void);
 int svo_ctx_create(int hip_device, svo_ctx **out);
 int svo_ctx_destroy(svo_ctx *ctx);
 /* Launch on a caller-owned hipStream_t (e.g. torch's current stream; NULL is HIP's default
@@ -156,6 +161,13 @@ int svo_nodes_scatter(svo_ctx *ctx, const uint32_t *indices, const uint32_t *hos
 int svo_nodes_read(svo_ctx *ctx, size_t word_offset, uint32_t *host_words, size_t n);
 /* Device pointer of the node buffer (for zero-copy consumers). */
 int svo_nodes_device_ptr(svo_ctx *ctx, uint32_t **out, size_t *capacity_words);
+
+/* Device memory for hit records, wire records and gathered frames, for hosts that carry no HIP binding of their own (the
+ * `*_out` parameters below are device pointers; any device pointer of the ctx's device will do).  svo_buffer_read copies
+ * to host memory behind everything enqueued on the ctx stream and blocks until done. */
+int svo_buffer_alloc(svo_ctx *ctx, size_t bytes, void **device_out);
+int svo_buffer_free(svo_ctx *ctx, void *device_ptr);
+int svo_buffer_read(svo_ctx *ctx, const void *device_ptr, void *host_out, size_t bytes);
 
 int svo_set_uniforms(svo_ctx *ctx, const svo_uniforms *u);
 

@@ -9,6 +9,7 @@
 #pragma once
 #include <cstdint>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -257,9 +258,99 @@ class Render {  // render.rs:3-285
     void render_host(svo_hit *hits, uint32_t *rgba = nullptr) {
         gpu_.check(svo_render_host(gpu_.ctx(), width, height, 0, 0, width, height, hits, rgba));
     }
+    // A second Render on another context of the same device over the SAME node buffer (svo_nodes_share): frames in
+    // flight on several streams.  Writes through either one are seen by both (shared generation counter).
+    struct Shared {};
+    Render(const Gpu &gpu, const Render &owner, Shared) : uniforms(owner.uniforms), width(owner.width), height(owner.height), gpu_(gpu) {
+        gpu_.check(svo_nodes_share(gpu_.ctx(), owner.gpu_.ctx()));
+        gpu_.check(svo_set_uniforms(gpu_.ctx(), &uniforms));
+    }
+    // this rank's tiles of a frame sharded over `world` GPUs (tile t belongs to rank t % world), contiguous in hits_dev
+    void render_tiles(uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world, svo_hit *hits_dev, uint32_t *rgba_dev = nullptr) {
+        gpu_.check(svo_render_tiles(gpu_.ctx(), width, height, tile_w, tile_h, rank, world, hits_dev, rgba_dev));
+    }
+    const Gpu &gpu() const { return gpu_; }
 
   private:
     const Gpu &gpu_;
+};
+
+// One process, one thread, N GPUs -- the reference's threading model (main.rs:40-88) extended to a tile-sharded frame
+// (SURVEY.md 8e): every device holds a replica of the node array and traces the tiles t = rank, rank + N, ...; the frame
+// ends with ONE gather of 12-byte wire records to device 0 over RCCL (svo_gather_frame_all) and the un-permute there.
+// Buffers live as long as the object; frame() returns a device pointer on device 0 that stays valid until the next frame().
+class MultiGpuFrame {
+  public:
+    MultiGpuFrame(const std::vector<int> &devices, uint32_t w, uint32_t h, const uint32_t *words, size_t n_words, size_t capacity,
+                  uint32_t tile_w = 64, uint32_t tile_h = 8)
+        : w_(w), h_(h), tw_(tile_w), th_(tile_h), world_(uint32_t(devices.size())) {
+        if (devices.empty() || w % tile_w || h % tile_h) throw Error(SVO_ERR_ARG, "frame must be a whole number of tiles");
+        const uint32_t tiles = (w / tile_w) * (h / tile_h);
+        n_pad_ = (tiles + world_ - 1) / world_;
+        for (int d : devices) {
+            gpus_.emplace_back(new Gpu(d));
+            renders_.emplace_back(new Render(*gpus_.back(), w, h, words, n_words, capacity));
+            ctxs_.push_back(gpus_.back()->ctx());
+        }
+        check(svo_comm_init_all(int(world_), ctxs_.data()));
+        const size_t rec = size_t(n_pad_) * tw_ * th_;
+        for (uint32_t r = 0; r < world_; r++) {
+            hits_.push_back(static_cast<svo_hit *>(dev_alloc(r, rec * sizeof(svo_hit))));
+            wire_.push_back(static_cast<uint32_t *>(dev_alloc(r, rec * 12)));
+        }
+        gathered_ = static_cast<uint32_t *>(dev_alloc(0, rec * 12 * world_));
+        frame_ = static_cast<svo_hit *>(dev_alloc(0, size_t(w) * h * sizeof(svo_hit)));
+    }
+    ~MultiGpuFrame() {
+        for (uint32_t r = 0; r < world_ && r < hits_.size(); r++) {
+            (void)svo_buffer_free(ctxs_[r], hits_[r]);
+            if (r < wire_.size()) (void)svo_buffer_free(ctxs_[r], wire_[r]);
+        }
+        if (!ctxs_.empty()) {
+            (void)svo_buffer_free(ctxs_[0], gathered_);
+            (void)svo_buffer_free(ctxs_[0], frame_);
+        }
+    }
+    MultiGpuFrame(const MultiGpuFrame &) = delete;
+    MultiGpuFrame &operator=(const MultiGpuFrame &) = delete;
+    // the assembled frame of the last frame() call, copied to host memory (blocking)
+    void read_frame(svo_hit *host) { check(svo_buffer_read(ctxs_[0], frame_, host, size_t(w_) * h_ * sizeof(svo_hit))); }
+    Render &render(uint32_t rank) { return *renders_[rank]; }
+    // trace every rank's tiles, gather, assemble: all asynchronous; sync() (or the next blocking call) completes it
+    svo_hit *frame() {
+        const size_t rec = size_t(n_pad_) * tw_ * th_;
+        std::vector<const void *> send(world_);
+        for (uint32_t r = 0; r < world_; r++) {
+            renders_[r]->render_tiles(tw_, th_, r, world_, hits_[r]);
+            check(svo_pack_records(ctxs_[r], hits_[r], rec, wire_[r]));
+            send[r] = wire_[r];
+        }
+        check(svo_gather_frame_all(int(world_), ctxs_.data(), send.data(), rec * 12, gathered_, 0));
+        check(svo_gather_wait(ctxs_[0]));
+        check(svo_assemble_tiles_packed(ctxs_[0], gathered_, world_, n_pad_, w_, h_, tw_, th_, frame_));
+        return frame_;
+    }
+    void sync() {
+        for (auto &g : gpus_) g->poll_wait();
+    }
+
+  private:
+    void check(int rc) const {
+        if (rc != SVO_OK) throw Error(rc, svo_last_error(ctxs_.empty() ? nullptr : ctxs_[0]));
+    }
+    void *dev_alloc(uint32_t rank, size_t bytes) {
+        void *p = nullptr;
+        check(svo_buffer_alloc(ctxs_[rank], bytes, &p));
+        return p;
+    }
+    uint32_t w_, h_, tw_, th_, world_, n_pad_ = 0;
+    std::vector<std::unique_ptr<Gpu>> gpus_;
+    std::vector<std::unique_ptr<Render>> renders_;
+    std::vector<svo_ctx *> ctxs_;
+    std::vector<svo_hit *> hits_;
+    std::vector<uint32_t *> wire_;
+    uint32_t *gathered_ = nullptr;
+    svo_hit *frame_ = nullptr;
 };
 
 class Compute {  // compute.rs:6-127 + the read-back of adaptive.rs:12-23, 76-87

@@ -38,7 +38,7 @@ class TerrainParams(C.Structure):
 
 
 DEVICE_SYMBOLS = [
-    "svo_ctx_create", "svo_ctx_destroy", "svo_ctx_set_stream", "svo_set_option", "svo_last_error", "svo_sync",
+    "svo_device_count", "svo_buffer_alloc", "svo_buffer_free", "svo_buffer_read", "svo_ctx_create", "svo_ctx_destroy", "svo_ctx_set_stream", "svo_set_option", "svo_last_error", "svo_sync",
     "svo_nodes_alloc", "svo_nodes_bind_device", "svo_nodes_write", "svo_nodes_scatter", "svo_nodes_read", "svo_nodes_device_ptr", "svo_nodes_share", "svo_nodes_invalidate",
     "svo_comm_unique_id", "svo_comm_init_rank", "svo_comm_init_all", "svo_comm_destroy", "svo_gather_frame", "svo_gather_frame_all", "svo_gather_wait",
     "svo_set_uniforms", "svo_render", "svo_render_host", "svo_render_tiles", "svo_render_secondary", "svo_render_tiles_secondary", "svo_assemble_tiles", "svo_assemble_tiles_packed", "svo_pack_records", "svo_trace_rays",
@@ -82,6 +82,10 @@ def lib():
         fn.argtypes = list(args)
 
     # device boundary (include/svo_hip.h)
+    sig("svo_device_count", C.c_int)
+    sig("svo_buffer_alloc", C.c_int, vp, sz, C.POINTER(vp))
+    sig("svo_buffer_free", C.c_int, vp, vp)
+    sig("svo_buffer_read", C.c_int, vp, vp, vp, sz)
     sig("svo_ctx_create", C.c_int, C.c_int, C.POINTER(vp))
     sig("svo_ctx_destroy", C.c_int, vp)
     sig("svo_ctx_set_stream", C.c_int, vp, vp, C.c_int)

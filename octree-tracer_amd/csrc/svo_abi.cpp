@@ -193,6 +193,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     a.aux_t = opt.aux_t;
     a.status = ctx->status;
     a.refill_min = ctx->refill_min;
+    a.cam_shortcut = ctx->cam_shortcut ? 1u : 0u;
     a.debug = ctx->debug_buf;
     a.skip = opt.skip;
     // shader.wgsl:159: counters are live unless pause_adaptive; rays handed in by the caller (svo_trace_rays) never count
@@ -511,6 +512,44 @@ int ensure_stage(svo_ctx *ctx, size_t bytes) {
 
 extern "C" {
 
+int svo_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int svo_buffer_alloc(svo_ctx *ctx, size_t bytes, void **device_out) {
+    if (!ctx || !device_out || bytes == 0) return SVO_ERR_ARG;
+    *device_out = nullptr;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMalloc(device_out, bytes));
+    return SVO_OK;
+}
+
+int svo_buffer_free(svo_ctx *ctx, void *device_ptr) {
+    if (!ctx) return SVO_ERR_ARG;
+    if (!device_ptr) return SVO_OK;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // work that still uses the buffer finishes first
+    if (ctx->comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
+    HIP_TRY(ctx, hipFree(device_ptr));
+    return SVO_OK;
+}
+
+int svo_buffer_read(svo_ctx *ctx, const void *device_ptr, void *host_out, size_t bytes) {
+    if (!ctx || ((!device_ptr || !host_out) && bytes)) return SVO_ERR_ARG;
+    int rc = bind(ctx);
+    if (rc || bytes == 0) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(host_out, device_ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SVO_OK;
+}
+
 int svo_ctx_create(int hip_device, svo_ctx **out) {
     if (!out) return SVO_ERR_ARG;
     *out = nullptr;
@@ -624,6 +663,9 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
         case SVO_OPT_TREE_DEPTH:
             if (value < 1 || value > 31) return fail(ctx, SVO_ERR_ARG, "tree depth must be 1..31");
             ctx->tree_depth = (uint32_t)value;  // (which kernel that means is decided per launch, see trace_launch)
+            return SVO_OK;
+        case SVO_OPT_CAMERA_SHORTCUT:
+            ctx->cam_shortcut = value != 0;
             return SVO_OK;
         case SVO_OPT_CULL:
             if (value < 0 || value > 2) return fail(ctx, SVO_ERR_ARG, "cull: 0 (off), 1 (whenever the camera is outside the cube) or 2 (automatic)");

@@ -44,6 +44,7 @@ struct svo_ctx {
     uint32_t *top_table = nullptr;
     int use_pairs = 0;           // SVO_OPT_PAIR_TABLE
     int cull_mode = 2;           // SVO_OPT_CULL
+    bool cam_shortcut = true;    // SVO_OPT_CAMERA_SHORTCUT
     void *comm = nullptr;        // ncclComm_t (svo_comm.cpp); world size and rank of this context in it
     int comm_world = 0, comm_rank = 0;
     hipStream_t comm_stream = nullptr;  // the gathers run here, ordered against `stream` by the two events

@@ -49,6 +49,7 @@ struct TraceArgs {
     float *aux_t;               // optional: t_current of the last step per record (the shading pass rebuilds HitInfo.pos)
     uint32_t *status;           // device word: bit 0 set when a STACK-variant descent exceeded kPathBits
     uint32_t refill_min;
+    uint32_t cam_shortcut;      // STACK: 1 = rays that start at the camera's own position inside the cube share the wave's one first walk
     uint32_t *count_nodes;      // writable alias of nodes when hit counters are live (pause_adaptive off), else nullptr
     const uint32_t *order;      // STACK, optional: schedule built by strip_order_kernel (8 lengths + 8 lists)
     uint32_t order_cap;         // entries reserved per list

@@ -763,6 +763,80 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
         st = 0u;
     };
 
+    // the one-level walk: one dependent word per level below (lvl, nidx), ancestors pushed on the lane's LDS stack
+    auto descend = [&]() {
+            uint32_t off, w, key;
+            uint32_t sh = (uint32_t)D - lvl + 1u;            // (bit of the path codes that selects the child) + 1
+            // slot of level lvl + 1; a descent that starts on a leaf above level K+1 (from the top table) pushes its
+            // one dead word into row 0, which is rewritten before any restart can read it
+            uint32_t sp = (uint32_t)TBL + (max(lvl, (uint32_t)(SBASE - 1)) - (uint32_t)(SBASE - 1)) * BLOCK + tid;
+            // straight-line body, one exit test: the push also happens on the exiting iteration (it lands in the
+            // slot below the leaf, which no restart reads; the stack has one spare row for an exit at level SMAX)
+            do {
+                if (DBG) {
+                    const uint64_t in_loop = __ballot(true);
+                    if (lane == (uint32_t)__ffsll((unsigned long long)in_loop) - 1u) {  // (tallies summed over lanes at the end)
+                        dbg_desc_iters += 1u;
+                        dbg_desc_lanes += (uint32_t)__popcll(in_loop);
+                    }
+                }
+                // sh -= 1 (level being read: D - sh); child = x << 2 | y << 1 | z; byte offset = (nidx + child) << 2.
+                // Three-operand forms the compiler does not pick by itself, in ONE asm statement (the compiler pads every
+                // inline-asm statement with an s_nop, and keeping the decrement inside saves a copy of the counter)
+                uint32_t tmp;
+                asm("v_add_u32 %2, -1, %2\n\t"
+                    "v_bfe_u32 %0, %3, %2, 1\n\t"
+                    "v_bfe_u32 %1, %4, %2, 1\n\t"
+                    "v_lshl_or_b32 %0, %0, 1, %1\n\t"
+                    "v_bfe_u32 %1, %5, %2, 1\n\t"
+                    "v_lshl_or_b32 %0, %0, 1, %1\n\t"
+                    "v_add_lshl_u32 %0, %6, %0, 2"
+                    : "=&v"(off), "=&v"(tmp), "+v"(sh)
+                    : "v"(ix), "v"(iy), "v"(iz), "v"(nidx));
+                w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
+                nidx = w >> 4;
+                lds[sp] = nidx;
+                sp += BLOCK;
+                // sign bit: a leaf (word >= VOXEL_OFFSET << 4), or level SMAX reached (deeper trees are refused)
+                key = w | (sh - (uint32_t)(D - SMAX + 1));
+            } while ((int32_t)key >= 0);
+            lvl = (uint32_t)D - sh;
+            leaf_off = off;
+            leaf_w = w;
+            st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
+            };
+
+    // Camera shortcut.  Every primary ray of a camera that stands INSIDE the cube starts at the same point, hence in the
+    // same leaf, with the same ancestors: the first walk of a ray -- the longest it ever makes, root to leaf, while the
+    // other lanes of the wave wait for it -- is the same for all of them.  The wave makes it once, here, all lanes alike,
+    // and keeps what it found in one register (lane l holds word l: the stack rows, then the leaf's word offset, the
+    // word and its level); a lane that picks up a ray copies it into its stack column instead of walking, and takes its
+    // first step in the same round.
+    // (Not with live hit counters: the copied leaf word would carry the counter bits it had when the wave started, and
+    // every ray's compare-and-swap on that one word would fail once -- two million serialised atomics on one address.)
+    constexpr bool CAM = !PAIRS && !CNT;
+    uint32_t camv = 0;
+    bool cam_ok = false;  // wave-uniform
+    if (CAM && a.cam_shortcut && a.work.mode != 2) {
+        const RayIn r0 = gen_ray(a.u, 0u, 0u);  // (the position does not depend on the pixel)
+        if (in_bounds(r0.px, r0.py, r0.pz)) {   // ray_enter: such rays start where they are, dist = 0
+            ix = entry_code<GE>(r0.px * kScale);
+            iy = entry_code<GE>(r0.py * kScale);
+            iz = entry_code<GE>(r0.pz * kScale);
+            st = ST_ACTIVE | ST_DESC;
+            restart_at(1u);
+            descend();
+            uint32_t v = lane < (uint32_t)NS ? lds[(uint32_t)TBL + lane * BLOCK + tid] : 0u;  // row `lane` of this lane's own column
+            v = lane == (uint32_t)NS ? leaf_off : v;
+            v = lane == (uint32_t)NS + 1u ? leaf_w : v;
+            v = lane == (uint32_t)NS + 2u ? lvl : v;
+            camv = v;
+            // worth it when the camera's leaf is deep (the copy at pick-up costs about two walk iterations)
+            cam_ok = (uint32_t)__builtin_amdgcn_readfirstlane(lvl) >= (uint32_t)(SBASE + 2);
+            st = 0u;
+        }
+    }
+
     for (;;) {
         if (DBG) c_mark = __builtin_amdgcn_s_memtime();
         if (DBG) {  // per-wave timeline build only (SVO_OPT_DEBUG_BUFFER): the default instantiation carries none of this
@@ -820,48 +894,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
             leaf_w = lw;
             st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
         }
-        if (!PAIRS && st >= (ST_ACTIVE | ST_DESC)) {  // DESC implies ACTIVE: one unsigned compare
-            uint32_t off, w, key;
-            uint32_t sh = (uint32_t)D - lvl + 1u;            // (bit of the path codes that selects the child) + 1
-            // slot of level lvl + 1; a descent that starts on a leaf above level K+1 (from the top table) pushes its
-            // one dead word into row 0, which is rewritten before any restart can read it
-            uint32_t sp = (uint32_t)TBL + (max(lvl, (uint32_t)(SBASE - 1)) - (uint32_t)(SBASE - 1)) * BLOCK + tid;
-            // straight-line body, one exit test: the push also happens on the exiting iteration (it lands in the
-            // slot below the leaf, which no restart reads; the stack has one spare row for an exit at level SMAX)
-            do {
-                if (DBG) {
-                    const uint64_t in_loop = __ballot(true);
-                    if (lane == (uint32_t)__ffsll((unsigned long long)in_loop) - 1u) {  // (tallies summed over lanes at the end)
-                        dbg_desc_iters += 1u;
-                        dbg_desc_lanes += (uint32_t)__popcll(in_loop);
-                    }
-                }
-                // sh -= 1 (level being read: D - sh); child = x << 2 | y << 1 | z; byte offset = (nidx + child) << 2.
-                // Three-operand forms the compiler does not pick by itself, in ONE asm statement (the compiler pads every
-                // inline-asm statement with an s_nop, and keeping the decrement inside saves a copy of the counter)
-                uint32_t tmp;
-                asm("v_add_u32 %2, -1, %2\n\t"
-                    "v_bfe_u32 %0, %3, %2, 1\n\t"
-                    "v_bfe_u32 %1, %4, %2, 1\n\t"
-                    "v_lshl_or_b32 %0, %0, 1, %1\n\t"
-                    "v_bfe_u32 %1, %5, %2, 1\n\t"
-                    "v_lshl_or_b32 %0, %0, 1, %1\n\t"
-                    "v_add_lshl_u32 %0, %6, %0, 2"
-                    : "=&v"(off), "=&v"(tmp), "+v"(sh)
-                    : "v"(ix), "v"(iy), "v"(iz), "v"(nidx));
-                w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
-                nidx = w >> 4;
-                lds[sp] = nidx;
-                sp += BLOCK;
-                // sign bit: a leaf (word >= VOXEL_OFFSET << 4), or level SMAX reached (deeper trees are refused)
-                key = w | (sh - (uint32_t)(D - SMAX + 1));
-            } while ((int32_t)key >= 0);
-            lvl = (uint32_t)D - sh;
-            leaf_off = off;
-            leaf_w = w;
-            st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
-        }
-
+        if (!PAIRS && st >= (ST_ACTIVE | ST_DESC)) descend();  // DESC implies ACTIVE: one unsigned compare
         if (DBG) {
             const uint64_t now = __builtin_amdgcn_s_memtime();
             c_desc += (uint32_t)(now - c_mark);
@@ -1005,8 +1038,19 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                         iy = entry_code<GE>(P1);
                         iz = entry_code<GE>(P2);
                         tcur = 0.0f;
-                        st = ST_ACTIVE | ST_DESC | ST_ENTRY;  // steps = 0, L = 0
-                        restart_at(1u);
+                        if (CAM && cam_ok && dist == 0.0f) {
+                            // a ray from the camera's own position: the walk the wave made at the start (see above)
+                            const uint32_t L0 = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 2);
+                            for (uint32_t l = 0; l < (uint32_t)NS && l + (uint32_t)SBASE <= L0; l++)
+                                lds[(uint32_t)TBL + l * BLOCK + tid] = (uint32_t)__builtin_amdgcn_readlane((int)camv, (int)l);
+                            leaf_off = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS);
+                            leaf_w = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 1);
+                            lvl = L0;
+                            st = ST_ACTIVE | ST_ENTRY | (L0 << ST_L_SHIFT);  // steps = 0, at its leaf
+                        } else {
+                            st = ST_ACTIVE | ST_DESC | ST_ENTRY;  // steps = 0, L = 0
+                            restart_at(1u);
+                        }
                     }
                 }
                 const uint32_t took = min(SHD ? 64u - (uint32_t)__popcll(act) : n_idle, pool_n);

@@ -21,11 +21,13 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--count", action="store_true", help="adaptive mode: also compare the hit counters after each frame (slower: the oracle counts on one thread)")
     ap.add_argument("--secondary", action="store_true", help="svo_render_secondary with 4 rays per hit pixel, random sun directions, ray 0 fused into the primary launch (SVO_OPT_FUSED_SHADOWS = 1): primary and secondary records against the oracle")
+    ap.add_argument("--cull", type=int, default=2, help="SVO_OPT_CULL (1: cull whenever the camera is outside the cube); every 8th pose then stands far away")
     ap.add_argument("--deep", action="store_true", help="deep trees instead (depth-20 fractal, depth-19 terrain): the 19-level stack instantiations, SVO_OPT_TREE_DEPTH = 20")
     a = ap.parse_args()
     pkg, O = entry.load_package(), entry.load_oracle()
     gpu = pkg.Gpu(0)
     gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+    gpu.set_option(pkg.gpu.OPT_CULL, a.cull)
     if a.secondary:
         gpu.set_option(pkg.gpu.OPT_FUSED_SHADOWS, 1)
     cam, look = pkg.scenes.terrain_camera(0, 16)
@@ -55,7 +57,7 @@ def main():
             if kind == 0:    # inside the cube
                 pos = rng.uniform(-0.95, 0.95, 3)
             elif kind == 1:  # outside, looking roughly at the cube
-                pos = rng.normal(size=3); pos = pos / np.linalg.norm(pos) * rng.uniform(1.2, 3.0)
+                pos = rng.normal(size=3); pos = pos / np.linalg.norm(pos) * (rng.uniform(3.0, 12.0) if k % 8 == 1 else rng.uniform(1.2, 3.0))
             elif kind == 2:  # on or near cell boundaries
                 pos = np.round(rng.uniform(-1, 1, 3) * 16) / 16 + rng.choice([0.0, 1e-7, -1e-7, 1e-3], 3)
             else:            # near a face of the cube
