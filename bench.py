@@ -158,14 +158,22 @@ def main():
     if pipelined and a.backend == "nccl":
         gather_mode = a.gather
         if gather_mode == "abi":
-            # one RCCL communicator per lane behind the C ABI; rank 0's ids travel over the launcher's process group
+            # one RCCL communicator per lane behind the C ABI; rank 0's ids travel over the launcher's process group.
+            # A rank on which the library cannot set one up (librccl missing, ...) says so before the collective call, and
+            # all ranks then fall back to torch.distributed's gather together.
+            ok = torch.tensor([1], dtype=torch.int32, device=f"cuda:{local_rank}")
             try:
+                pkg.Gpu.comm_unique_id()  # (loads librccl)
+            except pkg.SvoError:
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                gather_mode = "torch"
+            else:
                 for g, _, _ in lanes:
                     ids = [pkg.Gpu.comm_unique_id() if rank == 0 else None]
                     dist.broadcast_object_list(ids, src=0)
                     g.comm_init_rank(ids[0], world, rank)
-            except pkg.SvoError as e:  # (a rank-local failure: the other ranks would hang in the collective, so say it loudly)
-                raise SystemExit(f"rank {rank}: RCCL communicator behind the C ABI failed: {e}; rerun with --gather torch")
 
     def barrier():
         torch.cuda.synchronize()

@@ -175,3 +175,36 @@ def test_bench_line_fields(pkg, gpu):
     assert 0 < line["roofline_valu"]["frac"] < 1
     assert line["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] is True
     assert line["cpu_baseline"]["host_cores_total"] >= line["cpu_baseline"]["cores"]
+
+
+def test_adaptive_frame_time_stays_a_small_multiple_of_the_static_one(pkg, gpu):
+    """Guard against atomics pile-ups in the counting instantiation.  Round 2 found one only by profiling: a copied leaf word
+    with stale counter bits made every ray's compare-and-swap on the camera's leaf fail once -- 2 M serialised atomics,
+    38 x the static frame instead of 4 x -- while every parity test stayed green.  Kernel time from cleared counters must stay
+    under 12 x the static frame on a camera-inside view of a mid-size terrain."""
+    cam, look = pkg.scenes.terrain_camera(0, 16)
+    words = pkg.scenes.terrain(seed=0, max_depth=16, cam=cam, lod_c=600.0, max_words=40_000_000)
+    W, H = 1920, 1080
+    gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+    gpu.set_option(pkg.gpu.OPT_TIMING, 4)
+    try:
+        render = pkg.Render(gpu, (W, H), words, capacity=words.size)
+        hits = render.alloc_hits(W * H)
+
+        def frame_ms(clear, **flags):
+            render.set_flags(**flags)
+            render.update(pkg.Settings(), pkg.Character(cam, look))
+            ms = []
+            for i in range(6):
+                if clear:
+                    render.write_nodes(words)  # counters back to zero, as the reference's per-frame upload does
+                render.render(hits=hits)
+                gpu.sync()
+                ms.append(gpu.last_render_ms())
+            return float(np.median(ms[2:]))
+
+        static = frame_ms(False, pause_adaptive=True, shadows=False)
+        cleared = frame_ms(True, pause_adaptive=False, shadows=False)
+        assert cleared < 12.0 * static, f"adaptive frame from cleared counters {cleared:.2f} ms vs static {static:.2f} ms"
+    finally:
+        gpu.set_option(pkg.gpu.OPT_TIMING, 0)
