@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--block", default="3")
     ap.add_argument("--pairs", default="0")
     ap.add_argument("--cull", default="2")
+    ap.add_argument("--claim-at", default="64")
     ap.add_argument("--pose", type=int, default=0)
     ap.add_argument("--motion", type=float, default=0.0, help="degrees of yaw added to the camera every frame")
     a = ap.parse_args()
@@ -61,14 +62,22 @@ def main():
     hits = render.alloc_hits(a.w * a.h)
     n = a.w * a.h
     ref = None
-    for cull, pairs, blockw, variant, refill, strip, dyn, grid, prio, sched in itertools.product(
-            [int(x) for x in a.cull.split(",")], [int(x) for x in a.pairs.split(",")], [int(x) for x in a.block.split(",")],
+    for claim_at, cull, pairs, blockw, variant, refill, strip, dyn, grid, prio, sched in itertools.product(
+            [int(x) for x in a.claim_at.split(",")], [int(x) for x in a.cull.split(",")], [int(x) for x in a.pairs.split(",")], [int(x) for x in a.block.split(",")],
             [int(x) for x in a.variants.split(",")], [int(x) for x in a.refill.split(",")],
             [int(x) for x in a.strip.split(",")], [int(x) for x in a.dynamic.split(",")],
             [int(x) for x in a.grid.split(",")], [int(x) for x in a.prio.split(",")],
             [int(x) for x in a.schedule.split(",")]):
         if variant == 0 and (refill, strip, dyn) != (int(a.refill.split(",")[0]), int(a.strip.split(",")[0]), int(a.dynamic.split(",")[0])):
             continue
+        _set = gpu.set_option
+
+        def set_option(opt, val):  # (older library builds under A/B lack the newer options)
+            try:
+                _set(opt, val)
+            except Exception:
+                pass
+        gpu.set_option = set_option
         gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
         gpu.set_option(pkg.gpu.OPT_REFILL_MIN, refill)
         gpu.set_option(pkg.gpu.OPT_STRIP_ITEMS, strip)
@@ -79,6 +88,8 @@ def main():
         gpu.set_option(pkg.gpu.OPT_BLOCK_SHAPE, blockw)
         gpu.set_option(pkg.gpu.OPT_PAIR_TABLE, pairs)
         gpu.set_option(pkg.gpu.OPT_CULL, cull)
+        if hasattr(pkg.gpu, "OPT_CLAIM_AT"):
+            gpu.set_option(pkg.gpu.OPT_CLAIM_AT, claim_at)  # (experimental builds only)
         ms = []
         for i in range(a.reps + 2):
             if a.motion:
@@ -98,7 +109,7 @@ def main():
             ref = h.copy()
         same = bool(np.array_equal(ref, h)) if not a.motion else None
         med = float(np.median(ms))
-        print(json.dumps({"cull": cull, "pairs": pairs, "variant": variant, "refill": refill, "strip": strip, "dynamic": dyn, "grid": grid, "prio": prio, "schedule": sched, "block": blockw,
+        print(json.dumps({"claim_at": claim_at, "cull": cull, "pairs": pairs, "variant": variant, "refill": refill, "strip": strip, "dynamic": dyn, "grid": grid, "prio": prio, "schedule": sched, "block": blockw,
                           "ms_med": round(med, 4), "ms_min": round(min(ms), 4), "mrays_s": round(n / med / 1e3, 1),
                           "sig": sig, "same_as_first": same}), flush=True)
     steps = (ref[:, 2] & 0xFF)
