@@ -61,6 +61,12 @@ def main():
     gpu.set_option(pkg.gpu.OPT_TIMING, 1)
     hits = render.alloc_hits(a.w * a.h)
     n = a.w * a.h
+    def set_opt(opt, val):  # (older library builds under A/B lack the newer options)
+        try:
+            gpu.set_option(opt, val)
+        except Exception:
+            pass
+
     ref = None
     for claim_at, cull, pairs, blockw, variant, refill, strip, dyn, grid, prio, sched in itertools.product(
             [int(x) for x in a.claim_at.split(",")], [int(x) for x in a.cull.split(",")], [int(x) for x in a.pairs.split(",")], [int(x) for x in a.block.split(",")],
@@ -70,26 +76,18 @@ def main():
             [int(x) for x in a.schedule.split(",")]):
         if variant == 0 and (refill, strip, dyn) != (int(a.refill.split(",")[0]), int(a.strip.split(",")[0]), int(a.dynamic.split(",")[0])):
             continue
-        _set = gpu.set_option
-
-        def set_option(opt, val):  # (older library builds under A/B lack the newer options)
-            try:
-                _set(opt, val)
-            except Exception:
-                pass
-        gpu.set_option = set_option
-        gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
-        gpu.set_option(pkg.gpu.OPT_REFILL_MIN, refill)
-        gpu.set_option(pkg.gpu.OPT_STRIP_ITEMS, strip)
-        gpu.set_option(pkg.gpu.OPT_DYNAMIC_STRIPS, dyn)
-        gpu.set_option(pkg.gpu.OPT_GRID_BLOCKS, grid)
-        gpu.set_option(pkg.gpu.OPT_PRIO_STEPS, prio)
-        gpu.set_option(pkg.gpu.OPT_SCHEDULE, sched)
-        gpu.set_option(pkg.gpu.OPT_BLOCK_SHAPE, blockw)
-        gpu.set_option(pkg.gpu.OPT_PAIR_TABLE, pairs)
-        gpu.set_option(pkg.gpu.OPT_CULL, cull)
+        set_opt(pkg.gpu.OPT_VARIANT, variant)
+        set_opt(pkg.gpu.OPT_REFILL_MIN, refill)
+        set_opt(pkg.gpu.OPT_STRIP_ITEMS, strip)
+        set_opt(pkg.gpu.OPT_DYNAMIC_STRIPS, dyn)
+        set_opt(pkg.gpu.OPT_GRID_BLOCKS, grid)
+        set_opt(pkg.gpu.OPT_PRIO_STEPS, prio)
+        set_opt(pkg.gpu.OPT_SCHEDULE, sched)
+        set_opt(pkg.gpu.OPT_BLOCK_SHAPE, blockw)
+        set_opt(pkg.gpu.OPT_PAIR_TABLE, pairs)
+        set_opt(pkg.gpu.OPT_CULL, cull)
         if hasattr(pkg.gpu, "OPT_CLAIM_AT"):
-            gpu.set_option(pkg.gpu.OPT_CLAIM_AT, claim_at)  # (experimental builds only)
+            set_opt(pkg.gpu.OPT_CLAIM_AT, claim_at)  # (experimental builds only)
         ms = []
         for i in range(a.reps + 2):
             if a.motion:
