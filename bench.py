@@ -86,9 +86,11 @@ def main():
                          "frame's rays overlaps the next frames.  0 = default: 1 at N=1 (frames serial, which is what "
                          "roofline.* describes), 3 at N>1 (a rank's share of a sharded frame is too small to fill a GPU).  "
                          "More than 3 needs more hardware queues than ROCm's default of 4: GPU_MAX_HW_QUEUES=8 is set then")
-    ap.add_argument("--wire", default="packed12", choices=["packed12", "full16"],
+    ap.add_argument("--wire", default="packed12", choices=["packed12", "full16", "rgba8"],
                     help="N>1: what the frame-end gather carries per ray: the 12-byte wire record (the fourth word of svo_hit "
-                         "repeats bits of the third; rank 0 rebuilds it while un-permuting) or the full 16-byte record")
+                         "repeats bits of the third; rank 0 rebuilds it while un-permuting), the full 16-byte record, or -- rgba8 -- "
+                         "the shaded RGBA8 colour: the ranks shade their own tiles (fs_main, shadows as the uniforms say) and the "
+                         "frame that travels is the image the reference displays, 4 bytes per ray (the records stay on the ranks)")
     ap.add_argument("--force-pipeline", action="store_true",
                     help="validation: run the N>1 code path (lanes, wire records, RCCL gather, assemble) with a one-rank "
                          "process group on a single GPU")
@@ -206,7 +208,16 @@ def main():
             return step, None
         assert W % tw == 0 and H % th == 0
         # frame i's RCCL gather overlaps frame i+1's trace (double-buffered); rank 0 un-permutes each frame
-        if a.backend == "nccl":
+        if a.backend == "nccl" and a.wire == "rgba8":
+            n_pad_c = pkg.sharding.padded_tile_count(W, H, tw, th, world)
+            recs = [r.alloc_hits(n_pad_c * tw * th) for _, r, _ in lanes]  # this rank's records stay here
+            traces = [(lambda buf, r=r, h=h: r.render_tiles(tw, th, rank, world, hits=h, rgba=buf)) for (_, r, _), h in zip(lanes, recs)]
+            assemble = [(lambda g, out, r=r: r.assemble_tiles_rgba(g, tw, th, out=out)) for _, r, _ in lanes]
+            gather = [((lambda send, recv, g=g: g.gather_frame(send, recv, 0)), g.gather_wait) for g, _, _ in lanes] \
+                if gather_mode == "abi" else None
+            pipe = pkg.sharding.FramePipeline(traces, W, H, tw, th, rank, world, f"cuda:{local_rank}",
+                                              streams=[s for _, _, s in lanes], assemble=assemble, gather=gather, words=1)
+        elif a.backend == "nccl":
             traces = [(lambda buf, r=r: r.render_tiles(tw, th, rank, world, hits=buf)) for _, r, _ in lanes]
             assemble = [(lambda g, out, r=r: r.assemble_tiles(g, tw, th, out=out)) for _, r, _ in lanes]
             pack = [(lambda rec, wire, r=r: r.pack_records(rec, wire)) for _, r, _ in lanes] if a.wire == "packed12" else None
@@ -262,7 +273,10 @@ def main():
     n_rays = W * H
     elapsed, kms, out = measure(W, H, a.steps, a.warmup)
     gpu.sync()
-    frame = out.reshape(-1, 4).cpu().numpy().view(np.uint32) if rank == 0 else None
+    colour_wire = pipelined and a.wire == "rgba8"
+    if colour_wire and a.backend != "nccl":
+        raise SystemExit("--wire rgba8 needs --backend nccl")
+    frame = out.reshape(-1, 1 if colour_wire else 4).cpu().numpy().view(np.uint32) if rank == 0 else None
 
     # ---- beside the headline, same run, outside its timed region ----
     extras = {}
@@ -315,7 +329,8 @@ def main():
             sharding = "none"
         else:
             via = {"abi": "svo_gather_frame (RCCL behind the C ABI)", "torch": "torch.distributed.gather (RCCL)", None: "gloo via host memory"}[gather_mode]
-            sharding = (f"tiles {tw}x{th} round-robin, 1 gather per frame through {via}, {12 if a.wire == 'packed12' else 16} B/ray, "
+            sharding = (f"tiles {tw}x{th} round-robin, 1 gather per frame through {via}, "
+                        f"{ {'packed12': '12 B/ray (wire records)', 'full16': '16 B/ray (records)', 'rgba8': '4 B/ray (shaded RGBA8 colour; records stay on the ranks)'}[a.wire] }, "
                         "overlapped with the following frames' traces")
         result = {
             "metric": "Mrays/sec at 1920x1080, depth-16 SVO; achieved HBM GB/s vs peak",
@@ -358,8 +373,16 @@ def main():
             if bytes_per_ray is None or a.cpu_frac == 1:
                 bytes_per_ray = sample_bpr
             # parity of the frame the GPU just produced, on the sampled rows (checker, not the product)
-            got = frame.reshape(H, W, 4)[:rows].reshape(-1, 4)
-            parity = bool(np.array_equal(got, rec.view(np.uint32).reshape(-1, 4)))
+            if colour_wire:
+                # the assembled frame is the RGBA8 image: against the oracle's fs_main (pow() differs between libm and the GPU
+                # by at most one code value per channel, tests/test_parity_gpu.py::test_shaded_frame)
+                want = O.shade_frame(words, u, tile=(0, 0, W, rows), threads=cores)
+                want8 = np.floor(np.clip(want, 0, 1) * 255.0 + 0.5).astype(np.int32).reshape(-1, 4)
+                got8 = frame.reshape(H, W)[:rows].reshape(-1).view(np.uint8).reshape(-1, 4).astype(np.int32)
+                parity = bool(np.abs(got8 - want8).max() <= 1)
+            else:
+                got = frame.reshape(H, W, 4)[:rows].reshape(-1, 4)
+                parity = bool(np.array_equal(got, rec.view(np.uint32).reshape(-1, 4)))
             cpu = {"value": round(len(rec) * reps / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores,
                    "host_cores_available": host_cores, "host_cores_total": os.cpu_count(), "kind": "port",
                    "sample": f"rows 0..{rows - 1} of the same frame ({len(rec)} rays) traced {reps} times ({cpu_s:.1f} s), "

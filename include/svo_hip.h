@@ -236,6 +236,12 @@ int svo_gather_wait(svo_ctx *ctx);
  * recv_on_root lives on ctxs[root]'s device. */
 int svo_gather_frame_all(int n, svo_ctx *const *ctxs, const void *const *send, size_t bytes, void *recv_on_root, int root);
 
+/* The same un-permute for a gathered COLOUR frame: when the consumer of the sharded frame is a display -- the reference's
+ * output is the RGBA image of fs_main -- the ranks gather rgba_out of svo_render_tiles, 4 bytes per ray on the links instead
+ * of 12 (the gather into one GPU is what bounds an 8-GPU frame).  Device pointers. */
+int svo_assemble_tiles_rgba(svo_ctx *ctx, const uint32_t *gathered_rgba, uint32_t world, uint32_t n_pad, uint32_t width,
+                            uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t *rgba_frame_out);
+
 /* octree_ray over n explicit rays (6 floats each: pos.xyz, dir.xyz; device pointers). */
 int svo_trace_rays(svo_ctx *ctx, const float *rays, size_t n_rays, svo_hit *hits_out);
 

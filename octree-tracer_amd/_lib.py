@@ -41,7 +41,7 @@ DEVICE_SYMBOLS = [
     "svo_device_count", "svo_buffer_alloc", "svo_buffer_free", "svo_buffer_read", "svo_ctx_create", "svo_ctx_destroy", "svo_ctx_set_stream", "svo_set_option", "svo_last_error", "svo_sync",
     "svo_nodes_alloc", "svo_nodes_bind_device", "svo_nodes_write", "svo_nodes_scatter", "svo_nodes_read", "svo_nodes_device_ptr", "svo_nodes_share", "svo_nodes_invalidate",
     "svo_comm_unique_id", "svo_comm_init_rank", "svo_comm_init_all", "svo_comm_destroy", "svo_gather_frame", "svo_gather_frame_all", "svo_gather_wait",
-    "svo_set_uniforms", "svo_render", "svo_render_host", "svo_render_tiles", "svo_render_secondary", "svo_render_tiles_secondary", "svo_assemble_tiles", "svo_assemble_tiles_packed", "svo_pack_records", "svo_trace_rays",
+    "svo_set_uniforms", "svo_render", "svo_render_host", "svo_render_tiles", "svo_render_secondary", "svo_render_tiles_secondary", "svo_assemble_tiles", "svo_assemble_tiles_packed", "svo_assemble_tiles_rgba", "svo_pack_records", "svo_trace_rays",
     "svo_last_render_ms", "svo_timing_collect", "svo_diag_gather", "svo_scan_dispatch", "svo_scan_read",
 ]
 HOST_SYMBOLS = [
@@ -115,6 +115,7 @@ def lib():
     sig("svo_render_tiles_secondary", C.c_int, vp, u32, u32, u32, u32, u32, u32, u32, vp, vp)
     sig("svo_assemble_tiles", C.c_int, vp, vp, u32, u32, u32, u32, u32, u32, vp)
     sig("svo_assemble_tiles_packed", C.c_int, vp, vp, u32, u32, u32, u32, u32, u32, vp)
+    sig("svo_assemble_tiles_rgba", C.c_int, vp, vp, u32, u32, u32, u32, u32, u32, vp)
     sig("svo_pack_records", C.c_int, vp, vp, sz, vp)
     sig("svo_trace_rays", C.c_int, vp, vp, sz, vp)
     sig("svo_last_render_ms", C.c_int, vp, fp)

@@ -922,6 +922,20 @@ int svo_assemble_tiles_packed(svo_ctx *ctx, const uint32_t *gathered_wire, uint3
     return assemble_common(ctx, gathered_wire, true, world, n_pad, width, height, tile_w, tile_h, frame_out);
 }
 
+int svo_assemble_tiles_rgba(svo_ctx *ctx, const uint32_t *gathered_rgba, uint32_t world, uint32_t n_pad, uint32_t width, uint32_t height,
+                            uint32_t tile_w, uint32_t tile_h, uint32_t *rgba_frame_out) {
+    if (!ctx || !gathered_rgba || !rgba_frame_out) return SVO_ERR_ARG;
+    if (world == 0 || tile_w == 0 || tile_h == 0 || width % tile_w || height % tile_h)
+        return fail(ctx, SVO_ERR_ARG, "frame must be a whole number of tiles");
+    const uint64_t tiles = (uint64_t)(width / tile_w) * (height / tile_h);
+    if ((uint64_t)n_pad * world < tiles) return fail(ctx, SVO_ERR_ARG, "gathered buffer holds fewer tiles than the frame");
+    if ((uint64_t)width * height > (1u << 26)) return fail(ctx, SVO_ERR_ARG, "frame too large");
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, svo::launch_assemble_tiles_rgba(gathered_rgba, rgba_frame_out, world, n_pad, width, height, tile_w, tile_h, ctx->stream));
+    return SVO_OK;
+}
+
 int svo_pack_records(svo_ctx *ctx, const svo_hit *records, size_t n, uint32_t *wire_out) {
     if (!ctx || ((!records || !wire_out) && n)) return SVO_ERR_ARG;
     if (n > (1u << 26)) return fail(ctx, SVO_ERR_ARG, "too many records for one call");

@@ -102,6 +102,8 @@ hipError_t launch_scan(uint32_t *nodes, uint32_t n_words, uint32_t node_length, 
                        uint32_t capacity, bool clear_counters, hipStream_t stream);
 hipError_t launch_assemble_tiles(const void *gathered, bool packed, svo_hit *frame, uint32_t world, uint32_t n_pad, uint32_t width,
                                  uint32_t height, uint32_t tile_w, uint32_t tile_h, hipStream_t stream);
+hipError_t launch_assemble_tiles_rgba(const uint32_t *gathered, uint32_t *frame, uint32_t world, uint32_t n_pad, uint32_t width,
+                                      uint32_t height, uint32_t tile_w, uint32_t tile_h, hipStream_t stream);
 hipError_t launch_pack_records(const svo_hit *records, uint32_t *wire, uint32_t n, hipStream_t stream);
 hipError_t launch_scatter(uint32_t *nodes, uint32_t n_words, const uint32_t *indices, const uint32_t *words, uint32_t n,
                           hipStream_t stream);

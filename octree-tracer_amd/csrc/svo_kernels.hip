@@ -1878,6 +1878,29 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const uint4 *records,
     }
 }
 
+// The same un-permute for a gathered COLOUR frame (one RGBA8 word per pixel): the exchange of a sharded frame whose
+// consumer wants the image fs_main produces, not hit records -- 4 bytes per ray on the links instead of 12.
+__global__ __launch_bounds__(256) void assemble_tiles_rgba_kernel(const uint32_t *gathered, uint32_t *frame, uint32_t world, uint32_t n_pad,
+                                                                  uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h) {
+    const uint32_t tiles_x = width / tile_w, n = width * height;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t y = i / width, x = i - y * width;
+        const uint32_t ty = y / tile_h, tx = x / tile_w;
+        const uint32_t t = ty * tiles_x + tx, r = t % world, k = t / world;
+        frame[i] = gathered[((uint64_t)r * n_pad + k) * (tile_w * tile_h) + (y - ty * tile_h) * tile_w + (x - tx * tile_w)];
+    }
+}
+
+hipError_t launch_assemble_tiles_rgba(const uint32_t *gathered, uint32_t *frame, uint32_t world, uint32_t n_pad, uint32_t width,
+                                      uint32_t height, uint32_t tile_w, uint32_t tile_h, hipStream_t stream) {
+    (void)hipGetLastError();
+    uint32_t blocks = (width * height + 255u) / 256u;
+    if (blocks > 8192u) blocks = 8192u;
+    hipLaunchKernelGGL(assemble_tiles_rgba_kernel, dim3(blocks), dim3(256), 0, stream, gathered, frame, world, n_pad, width, height, tile_w,
+                       tile_h);
+    return hipGetLastError();
+}
+
 hipError_t launch_assemble_tiles(const void *gathered, bool packed, svo_hit *frame, uint32_t world, uint32_t n_pad, uint32_t width,
                                  uint32_t height, uint32_t tile_w, uint32_t tile_h, hipStream_t stream) {
     (void)hipGetLastError();

@@ -168,6 +168,16 @@ class Render:
         self.gpu.check(fn(self.gpu._h, gathered.data_ptr(), world, n_pad, w, h, tile_w, tile_h, out.data_ptr()))
         return out
 
+    def assemble_tiles_rgba(self, gathered, tile_w, tile_h, out=None):
+        """Rank 0: un-permute a gathered COLOUR frame ([world, n_pad, tile_h * tile_w] int32 RGBA8, device) into [H, W]
+        (svo_assemble_tiles_rgba)."""
+        w, h = self.size
+        world, n_pad = int(gathered.shape[0]), int(gathered.shape[1])
+        if out is None:
+            out = torch.empty((h, w), dtype=torch.int32, device=gathered.device)
+        self.gpu.check(lib().svo_assemble_tiles_rgba(self.gpu._h, gathered.data_ptr(), world, n_pad, w, h, tile_w, tile_h, out.data_ptr()))
+        return out
+
     def pack_records(self, records, wire):
         """[..., 4] int32 hit records -> [..., 3] int32 wire records (svo_pack_records), on this context's stream."""
         n = records.numel() // 4

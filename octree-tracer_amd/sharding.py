@@ -48,12 +48,12 @@ def assemble_frame(gathered, width, height, tile_w, tile_h):
     (last dimension 3) are expanded on the way."""
     if gathered.shape[-1] == 3:
         gathered = unpack_records(gathered)
-    world, n_pad = gathered.shape[0], gathered.shape[1]
+    world, n_pad, c = gathered.shape[0], gathered.shape[1], gathered.shape[-1]  # c: 4 (records) or 1 (RGBA8 colour)
     tiles_x, tiles_y = width // tile_w, height // tile_h
     n = tiles_x * tiles_y
     # slot-major order is tile order: tile t = k * world + r
-    by_tile = gathered.permute(1, 0, 2, 3).reshape(n_pad * world, tile_h, tile_w, 4)[:n]
-    return by_tile.reshape(tiles_y, tiles_x, tile_h, tile_w, 4).permute(0, 2, 1, 3, 4).reshape(height, width, 4)
+    by_tile = gathered.permute(1, 0, 2, 3).reshape(n_pad * world, tile_h, tile_w, c)[:n]
+    return by_tile.reshape(tiles_y, tiles_x, tile_h, tile_w, c).permute(0, 2, 1, 3, 4).reshape(height, width, c)
 
 
 class FramePipeline:
@@ -73,7 +73,7 @@ class FramePipeline:
     buffers); drain() completes what is in flight and returns the last frame."""
 
     def __init__(self, trace, width, height, tile_w, tile_h, rank, world, device, group=None, streams=None, assemble=None,
-                 pack=None, gather=None):
+                 pack=None, gather=None, words=4):
         """assemble (optional, rank 0): one callable per lane, `assemble(gathered, out) -> out`, that un-permutes a gathered
         frame on the lane's stream (Render.assemble_tiles: one kernel, a few microseconds of host time); without it the
         generic torch expression assemble_frame() is used."""
@@ -81,6 +81,11 @@ class FramePipeline:
         # rank's part of the frame-end gather behind the lane's stream (Gpu.gather_frame: RCCL behind the C ABI,
         # svo_gather_frame), the second makes the lane's stream wait for it (Gpu.gather_wait).  Without it the exchange is
         # torch.distributed's gather on the default process group (RCCL as well on the GPU box, gloo in the CPU tests)
+        # words: int32 words per pixel slot of what `trace` produces: 4 = hit records (the default), 1 = RGBA8 colour (the
+        # ranks shade their tiles and the frame that travels is the image, 4 bytes per ray; no packing then)
+        self.words = words
+        if words not in (1, 4) or (words == 1 and pack):
+            raise ValueError("words must be 4 (records; optionally packed to 3 on the wire) or 1 (RGBA8, never packed)")
         self.gather = list(gather) if gather is not None else None
         self.traces = list(trace) if isinstance(trace, (list, tuple)) else [trace]
         self.assemble = list(assemble) if assemble is not None else None
@@ -94,13 +99,13 @@ class FramePipeline:
         self.dims = (width, height, tile_w, tile_h)
         self.n_buf = max(2, len(self.traces))  # a lone lane is still double-buffered against its gather
         n_pad = padded_tile_count(width, height, tile_w, tile_h, world)
-        self.local = [torch.zeros((n_pad, tile_h * tile_w, 4), dtype=torch.int32, device=device) for _ in range(self.n_buf)]
-        words = 3 if pack else 4
+        self.local = [torch.zeros((n_pad, tile_h * tile_w, words), dtype=torch.int32, device=device) for _ in range(self.n_buf)]
+        words = 3 if pack else words
         self.wire = [torch.zeros((n_pad, tile_h * tile_w, 3), dtype=torch.int32, device=device) if pack else None
                      for _ in range(self.n_buf)]
         self.gathered = [torch.empty((world, n_pad, tile_h * tile_w, words), dtype=torch.int32, device=device)
                          if rank == 0 else None for _ in range(self.n_buf)]
-        self.frames = [torch.empty((height, width, 4), dtype=torch.int32, device=device) if (rank == 0 and self.assemble) else None
+        self.frames = [torch.empty((height, width, self.words), dtype=torch.int32, device=device) if (rank == 0 and self.assemble) else None
                        for _ in range(self.n_buf)]
         self.recv = [list(g.unbind(0)) if g is not None else None for g in self.gathered]  # gather's output list, built once
         self.work = [None] * self.n_buf

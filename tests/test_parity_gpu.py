@@ -264,6 +264,19 @@ def test_assemble_tiles_kernel(pkg, gpu):
         render.assemble_tiles(g[:1], tw, th)  # fewer tiles than the frame has
 
 
+def test_assemble_tiles_rgba_kernel(pkg, gpu):
+    """svo_assemble_tiles_rgba against the torch expression of the sharding module (colour frames, one word per pixel)."""
+    import torch
+    W, H, tw, th, world = 192, 48, 64, 8, 5
+    n_pad = pkg.sharding.padded_tile_count(W, H, tw, th, world)
+    g = torch.randint(-2**31, 2**31 - 1, (world, n_pad, th * tw), dtype=torch.int32, device="cuda")
+    render = pkg.Render(gpu, (W, H), np.zeros(8, dtype=np.uint32), capacity=64)
+    got = render.assemble_tiles_rgba(g, tw, th)
+    gpu.sync()
+    want = pkg.sharding.assemble_frame(g.unsqueeze(-1), W, H, tw, th)[..., 0]
+    assert torch.equal(got, want)
+
+
 def test_frame_pipeline_nccl_single_rank(pkg, gpu):
     """bench.py's N > 1 loop (lanes on separate HIP streams, async RCCL gather, svo_assemble_tiles) with a one-rank
     process group: every completed frame equals the directly rendered one.  (More ranks need more GPUs; the rank
@@ -876,3 +889,9 @@ def test_bench_multi_gpu_path_with_one_rank(pkg, gpu):
     assert line["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] is True
     assert line["config"]["frames_in_flight"] == 3 and "12 B/ray" in line["config"]["sharding"]
     assert line["steps"] == 24 and line["value"] > 100
+    # the same path carrying the shaded colour frame instead of records (4 bytes per ray on the links)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-pipeline", "--wire", "rgba8", "--steps", "12", "--warmup", "2",
+                        "--no-extras"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] is True and "4 B/ray" in line["config"]["sharding"]

@@ -93,6 +93,18 @@ def _worker(rank, world, port, W, H, tw, th, out_path):
                 ok = ok and bool(np.array_equal(done[k].numpy().view(np.uint32), marked(k - 2)))
             ok = ok and done[2] is None
             ok = ok and bool(np.array_equal(last.numpy().view(np.uint32), marked(7)))
+        # colour frames (bench.py --wire rgba8): one RGBA8 word per pixel travels instead of records
+        colour = (local[..., 0:1] * 7 + 3).contiguous()  # any per-pixel word
+
+        def colour_trace(buf):
+            buf.copy_(colour)
+
+        pipe = sh.FramePipeline(colour_trace, W, H, tw, th, rank, world, "cpu", words=1)
+        for k in range(3):
+            pipe.step()
+        last = pipe.drain()
+        if rank == 0:
+            ok = ok and last.shape == (H, W, 1) and bool(np.array_equal(last.numpy().view(np.uint32)[..., 0], want[..., 0] * np.uint32(7) + np.uint32(3)))
             np.save(out_path, np.array([int(ok)]))
     finally:
         dist.destroy_process_group()
