@@ -118,8 +118,8 @@ typedef enum svo_option {
                                 4.5).  Results do not depend on it. */
     SVO_OPT_CULL = 14,       /* pixel frames, STACK variant: 64-pixel blocks whose rays all miss the cube (decided conservatively from
                                 the block's corner rays) get their all-zero records from a pre-pass and are never claimed by the
-                                trace.  0 off, 1 whenever the camera is outside the cube, 2 (default) when in addition the cube's
-                                projection leaves part of the screen empty.  Results do not depend on it. */
+                                trace.  0 off, 1 whenever the camera is outside the cube, 2 (default) when in addition at least 40 % of a
+                                coarse grid of rays tested on the host look past the cube.  Results do not depend on it. */
     SVO_OPT_CAMERA_SHORTCUT = 15, /* pixel frames, camera inside the cube, STACK variant: every primary ray starts in the camera's leaf, so a wave
                                 walks from the root to it once and its lanes copy that walk when they pick up a ray.  1 (default) on, 0 off.
                                 Results do not depend on it. */
