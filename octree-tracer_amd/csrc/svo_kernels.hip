@@ -550,7 +550,7 @@ constexpr int kPoolWords = 11;
 // PAIRS: descend through the pair table, two levels per load (static trees; never together with CNT, which needs the
 // address of every word on the path).
 template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD, bool PAIRS>
-__global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
+__global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
@@ -578,7 +578,9 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
     uint32_t *tbl = lds;                          // TBL entries
     uint32_t *stk = lds + TBL;                    // [NS][BLOCK]
     uint32_t *pool_all = stk + (NS + 1) * BLOCK;  // [BLOCK / 64][kPoolWords][64] (one spare stack row, see the descent)
-    uint32_t *aux = pool_all + (BLOCK / 64) * (kPoolWords * 64);  // CNT: level-1 / level-2 cell -> child group (kTopAuxEntries)
+    // CNT: level-1 / level-2 cell -> child group (kTopAuxEntries words behind the top table): read from global memory, where the
+    // 288 bytes stay in the L1 -- in LDS they cost the sixth workgroup per CU (the allocation granule)
+    const uint32_t *aux = a.top_table + TBL;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -588,7 +590,6 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
     const rsrc_t rp = PAIRS ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.pairs), 0, (int)((a.n_words + 1u) << 5), 0x00020000) : rs;
 
     for (uint32_t i = tid; i < (uint32_t)TBL; i += BLOCK) tbl[i] = a.top_table[i];
-    if (CNT && tid < (uint32_t)kTopAuxEntries) aux[tid] = a.top_table[(uint32_t)TBL + tid];
     __syncthreads();
 
     const uint32_t n_items = a.work.n_items;
@@ -1660,7 +1661,7 @@ static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipS
                                          : (pairs ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false, true>
                                                   : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false, false>)));
     size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
-                                (args.count_nodes ? kTopAuxEntries : 0)) * sizeof(uint32_t);
+                                0) * sizeof(uint32_t);
     // cached per context (= per device): [deep stack?][fused shadows?][counting instantiation?]
     int &blocks_per_cu = li.occupancy[(pairs ? 8 : 0) + (NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
     if (blocks_per_cu == 0) {
