@@ -196,12 +196,15 @@ __device__ __forceinline__ RayIn item_ray(const TraceArgs &a, const Item &it) {
 // n.data[p] = value + 1`.  The reference's plain read-modify-write races between rays; here the increment is a
 // compare-and-swap that stops at 15, so the counters after a frame are min(15, old + visits) whatever the
 // order (the oracle's oracle_count_frame).  Words saturate after 15 visits and are then only read.
-__device__ __forceinline__ void count_add(uint32_t *nodes, uint32_t p, uint32_t word, uint32_t n) {
+// Returns the counter as this call leaves or finds it.
+__device__ __forceinline__ uint32_t count_add(uint32_t *nodes, uint32_t p, uint32_t word, uint32_t n) {
     while ((word & 15u) < 15u) {
-        const uint32_t seen = atomicCAS(&nodes[p], word, word + min(n, 15u - (word & 15u)));
-        if (seen == word) break;
+        const uint32_t add = min(n, 15u - (word & 15u));
+        const uint32_t seen = atomicCAS(&nodes[p], word, word + add);
+        if (seen == word) return (word & 15u) + add;
         word = seen;
     }
+    return 15u;
 }
 
 // Called by all lanes that are at the same level of their descent.  Rays of a wave are coherent: near the root all 64
@@ -211,10 +214,12 @@ __device__ __forceinline__ void count_add(uint32_t *nodes, uint32_t p, uint32_t 
 // trace neighbouring pixels, so equal addresses mostly sit in runs of adjacent lanes: with few runs the groups are
 // exact (one ballot per distinct address merges runs that share a word), with many runs every run is its own group
 // (no loop; two runs on one word then cost two atomics, which is still correct).
-__device__ __forceinline__ void count_visit(uint32_t *nodes, uint32_t n_words, uint32_t p, uint32_t word) {
+// visit_groups: the number of visits this lane reports for word p -- the size of its group on the group's first lane, 0 on
+// every other lane (and on lanes whose word is saturated or outside the buffer).
+__device__ __forceinline__ uint32_t visit_groups(uint32_t n_words, uint32_t p, uint32_t word) {
     const bool need = p < n_words && (word & 15u) < 15u;
     const uint64_t needmask = __ballot(need);
-    if (!needmask) return;
+    if (!needmask) return 0u;
     const uint32_t lane = __lane_id();
     const uint32_t prev = (uint32_t)__shfl_up((int)p, 1);  // only looked at when lane - 1 is in needmask
     const bool head = need && (lane == 0u || !((needmask >> (lane - 1u)) & 1ull) || prev != p);
@@ -235,6 +240,11 @@ __device__ __forceinline__ void count_visit(uint32_t *nodes, uint32_t n_words, u
         const uint32_t end = stop ? (uint32_t)__ffsll((unsigned long long)stop) - 1u : 64u;
         if (head) n = end - lane;
     }
+    return n;
+}
+
+__device__ __forceinline__ void count_visit(uint32_t *nodes, uint32_t n_words, uint32_t p, uint32_t word) {
+    const uint32_t n = visit_groups(n_words, p, word);
     if (n) count_add(nodes, p, word, n);
 }
 
@@ -526,7 +536,7 @@ __device__ __forceinline__ bool clean_component(float p, float d) {
 
 // Per-lane state word: bits 0..7 steps | 8..12 leaf depth L | 13..15 step mask (axes of the last step's
 // normal) | 16 normal-is-entry-normal | 31 active | 30 needs descent (only ever set together with active) | 21 record pending | 22..24 how it ended
-constexpr uint32_t ST_L_SHIFT = 8, ST_M_SHIFT = 13, ST_SAT_SHIFT = 25;  // bits 25..29: see step 3a (counting instantiation)
+constexpr uint32_t ST_L_SHIFT = 8, ST_M_SHIFT = 13;
 constexpr uint32_t ST_ENTRY = 1u << 16, ST_ACTIVE = 1u << 31, ST_DESC = 1u << 30;
 constexpr uint32_t ST_SHADOW = 1u << 17;  // SHD instantiation: the lane traces the shadow ray of the pixel in `out`
 // a finished ray keeps its state until the lane is refilled: record not yet written + how it ended
@@ -541,6 +551,8 @@ constexpr uint32_t ST_L_MASK = 31u << ST_L_SHIFT, ST_M_MASK = 7u << ST_M_SHIFT;
 // grid units, see below), dist, out | entry normal code << 26.  (The entry path codes are recomputed at pick-up:
 // 11 words per ray keep a workgroup at 26 KiB of LDS, i.e. 6 workgroups per CU.)
 constexpr int kPoolWords = 11;
+constexpr int kCountQueue = 128;  // CNT: queued (word, visits) pairs per wave
+constexpr int kSatTags = 512;     // CNT: words known to be saturated, direct-mapped, per workgroup
 
 // The traversal runs in GRID UNITS: positions and directions are pre-multiplied by 2^23 (the path-code
 // scale).  Scaling by a power of two commutes with every IEEE rounding involved (no overflow/underflow on
@@ -550,7 +562,7 @@ constexpr int kPoolWords = 11;
 // PAIRS: descend through the pair table, two levels per load (static trees; never together with CNT, which needs the
 // address of every word on the path).
 template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD, bool PAIRS>
-__global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
+__global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
@@ -586,6 +598,51 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
     const uint32_t lane = tid & 63u;
     uint32_t *pool = pool_all + (tid >> 6) * (kPoolWords * 64);
     const rsrc_t rs = make_rsrc(a.nodes, a.n_words);
+    uint32_t c_refill = 0, c_desc = 0, c_step = 0, c_gen = 0, dbg_desc_iters = 0, dbg_desc_lanes = 0, dbg_desc_rounds = 0, dbg_desc_start = 0;
+    // CNT: the visits of a round are not added to the counters on the spot -- a compare-and-swap is executed at the memory
+    // side (the L2s of the 8 XCDs are not coherent with each other), its answer takes 0.4 - 1.3 us under this kernel's load,
+    // and a round that waits for one answer per level took 8 us instead of 2.  Final counters are min(15, old + visits) in
+    // whatever order the visits arrive, so every wave queues its (word, visits) pairs in LDS and adds them 64 at a time,
+    // all lanes in parallel: one wait per 64 - 192 pairs instead of one per level and round.
+    // What a lane learns only there -- that a word has reached 15 -- goes into a direct-mapped table of word indices shared
+    // by the workgroup (exact: an entry is the index itself); step 3a looks a word up before it queues a visit, so the
+    // hundreds of later visits of a word near the root cost one LDS read each, on whichever lane and ray they happen.
+    uint32_t *cq = pool_all + (BLOCK / 64) * (kPoolWords * 64) + (tid >> 6) * kCountQueue;  // (CNT only: the launch allocates both)
+    uint32_t *sat_tags = pool_all + (BLOCK / 64) * (kPoolWords * 64) + (BLOCK / 64) * kCountQueue;
+    auto sat_slot = [](uint32_t p) -> uint32_t { return (p * 2654435761u) >> 23; };  // kSatTags = 512
+    if (CNT) {
+        for (uint32_t i = tid; i < (uint32_t)kSatTags; i += BLOCK) sat_tags[i] = 0xFFFFFFFFu;
+        __syncthreads();
+    }
+    uint32_t cq_n = 0u;
+    auto cq_flush = [&]() {
+        for (uint32_t base = 0u; base < cq_n; base += 64u) {
+            const uint32_t i = base + (tid & 63u);
+            if (i < cq_n) {
+                const uint32_t rec = cq[i];
+                const uint32_t p = rec & 0x07FFFFFFu;
+                // (a device-scope load: the copy in this XCD's L2 is as old as its last miss, and a stale word costs a failed
+                // compare-and-swap -- the memory side's atomic rate, 24 G/s for the whole device, is what this mode runs against)
+                const uint32_t fresh = __hip_atomic_load(a.count_nodes + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (count_add(a.count_nodes, p, fresh, rec >> 27) == 15u) sat_tags[sat_slot(p)] = p;
+            }
+        }
+        cq_n = 0u;
+    };
+    // all lanes call this (uniform control flow); `mine` = the lane has a visit of word p (value `word`) to report
+    auto cq_push = [&](bool mine, uint32_t p, uint32_t word) {
+        const uint32_t n = visit_groups(a.n_words, p, mine ? word : 15u);
+        const uint64_t m = __ballot(n != 0u);
+        if (!m) return;
+        if (cq_n > (uint32_t)kCountQueue - 64u) {
+            if (DBG) dbg_desc_rounds += 1u;  // (CNT: slot 14 = queue flushes, slot 13 = cycles in them)
+            const uint64_t c_f0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
+            cq_flush();
+            if (DBG && lane == 0u) dbg_desc_lanes += (uint32_t)(__builtin_amdgcn_s_memtime() - c_f0);
+        }
+        if (n) cq[cq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = p | (min(n, 15u) << 27);
+        cq_n += (uint32_t)__popcll(m);
+    };
     // the pair table: (n_words + 1) rows of 32 bytes (the host keeps n_words + 1 below 2^27, so byte offsets fit 32 bits)
     const rsrc_t rp = PAIRS ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.pairs), 0, (int)((a.n_words + 1u) << 5), 0x00020000) : rs;
 
@@ -661,7 +718,6 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
     uint32_t n_rounds = 0, dbg_active = 0, dbg_iters = 0, dbg_refills = 0, dbg_gens = 0;
     // phase clocks of the timeline build (shader cycles, s_memtime): refill / descent / step, and the descent's shape
     uint64_t c_mark = 0;
-    uint32_t c_refill = 0, c_desc = 0, c_step = 0, c_gen = 0, dbg_desc_iters = 0, dbg_desc_lanes = 0, dbg_desc_rounds = 0, dbg_desc_start = 0;
     if (DBG) t_begin = __builtin_amdgcn_s_memrealtime();
 
     // per-lane ray state
@@ -673,6 +729,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
     int32_t ix = 0, iy = 0, iz = 0;
     uint32_t lvl = 1, nidx = 0;       // next level to read and the child group it lives in
     uint32_t leaf_off = 0, leaf_w = 0;  // current leaf: byte offset of its word, and the word
+    uint32_t satm = 0;                // CNT: bit l = the word of level l on the lane's current path is known to be saturated (step 3a)
 
     // (re)start a descent: from the LDS top table when the restart level r is at most K+1 (the table also
     // knows leaves that cover a whole level-K cell), else from the lane's ancestor stack.  One LDS read.
@@ -737,7 +794,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                 }
             }
             if (go) {
-                const uint32_t L_old = (st >> ST_L_SHIFT) & 31u, sat_old = (st >> ST_SAT_SHIFT) & 31u;
+                const uint32_t L_old = (st >> ST_L_SHIFT) & 31u;
                 P0 = pos2[0] * kScale; P1 = pos2[1] * kScale; P2 = pos2[2] * kScale;
                 Dr0 = sDr0; Dr1 = sDr1; Dr2 = sDr2;  // the same for every shadow ray
                 Y0 = sY0; Y1 = sY1; Y2 = sY2;
@@ -755,7 +812,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                 ix = jx; iy = jy; iz = jz;
                 const uint32_t r = max(min(min(c + 1u, L_old), (uint32_t)SMAX), 1u);
                 st = ST_ACTIVE | ST_DESC | ST_ENTRY | ST_SHADOW;
-                if (CNT) st |= min(sat_old, r - 1u) << ST_SAT_SHIFT;
+                if (CNT) satm &= (1u << r) - 1u;
                 restart_at(r);
                 return;
             }
@@ -777,8 +834,8 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                 if (DBG) {
                     const uint64_t in_loop = __ballot(true);
                     if (lane == (uint32_t)__ffsll((unsigned long long)in_loop) - 1u) {  // (tallies summed over lanes at the end)
-                        dbg_desc_iters += 1u;
-                        dbg_desc_lanes += (uint32_t)__popcll(in_loop);
+                        if (!CNT) dbg_desc_iters += 1u;
+                        if (!CNT) dbg_desc_lanes += (uint32_t)__popcll(in_loop);
                     }
                 }
                 // sh -= 1 (level being read: D - sh); child = x << 2 | y << 1 | z; byte offset = (nidx + child) << 2.
@@ -795,6 +852,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                     : "=&v"(off), "=&v"(tmp), "+v"(sh)
                     : "v"(ix), "v"(iy), "v"(iz), "v"(nidx));
                 w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
+                if (CNT) satm |= ((w & 15u) == 15u ? 1u : 0u) << ((uint32_t)D - sh);  // (a counter never goes down within a frame)
                 nidx = w >> 4;
                 lds[sp] = nidx;
                 sp += BLOCK;
@@ -843,8 +901,8 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
         if (DBG) {  // per-wave timeline build only (SVO_OPT_DEBUG_BUFFER): the default instantiation carries none of this
             n_rounds += 1;
             const uint32_t nd = (uint32_t)__popcll(__ballot(st >= (ST_ACTIVE | ST_DESC)));
-            dbg_desc_start += nd;
-            dbg_desc_rounds += nd ? 1u : 0u;
+            if (!CNT) dbg_desc_start += nd;
+            if (!CNT) dbg_desc_rounds += nd ? 1u : 0u;
         }
         // ---- 1. descent: one dependent word per level below the restart level (PAIRS: per two levels) ----
         if (PAIRS && st >= (ST_ACTIVE | ST_DESC)) {
@@ -857,8 +915,8 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                 if (DBG) {
                     const uint64_t in_loop = __ballot(true);
                     if (lane == (uint32_t)__ffsll((unsigned long long)in_loop) - 1u) {
-                        dbg_desc_iters += 1u;
-                        dbg_desc_lanes += (uint32_t)__popcll(in_loop);
+                        if (!CNT) dbg_desc_iters += 1u;
+                        if (!CNT) dbg_desc_lanes += (uint32_t)__popcll(in_loop);
                     }
                 }
                 // levels a = D - (sh - 1) and a + 1: child choices c1, c2 from the path codes
@@ -1050,6 +1108,7 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                             st = ST_ACTIVE | ST_ENTRY | (L0 << ST_L_SHIFT);  // steps = 0, at its leaf
                         } else {
                             st = ST_ACTIVE | ST_DESC | ST_ENTRY;  // steps = 0, L = 0
+                            if (CNT) satm = 0u;
                             restart_at(1u);
                         }
                     }
@@ -1074,19 +1133,28 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
             c_refill += (uint32_t)(now - c_mark);
             c_mark = now;
         }
-        // ---- 3. hit test / DDA step (shader.wgsl:215-244), clean rays, grid units ----
-        if ((st ^ ST_DESC) >= (ST_ACTIVE | ST_DESC)) {  // ST_ACTIVE and not ST_DESC: at a leaf (rays picked up above descend first)
-            const uint32_t L = (st >> ST_L_SHIFT) & 31u;
-            if (CNT) {
-                // ---- 3a. hit counters.  The reference's find_voxel bumps every word from the root to the leaf, once per
-                // call, i.e. once per round here (shader.wgsl:157-161); this kernel does not walk those words, but it
-                // knows their addresses: child group of level l (the top tables up to level K+1, the lane's stack below)
-                // + child index from the path codes.  A counter stops at 15, and near the root that happens within the
-                // first rounds of a frame, so each lane remembers up to which level the words of its current path are
-                // known to be saturated (ST_SAT; a restart at level r keeps that knowledge for levels < r) and only
-                // looks at the levels below.  Final counters = min(15, old + visits), like the RESTART kernel.
-                uint32_t sat = (st >> ST_SAT_SHIFT) & 31u;
-                for (uint32_t l = sat + 1u; l < L; l++) {  // (per lane; after the first rounds of a frame: none or one)
+        if (CNT) {
+            // ---- 3a. hit counters.  The reference's find_voxel bumps every word from the root to the leaf, once per
+            // call, i.e. once per round here (shader.wgsl:157-161); this kernel does not walk those words, but it
+            // knows their addresses: child group of level l (the top tables up to level K+1, the lane's stack below)
+            // + child index from the path codes.  A counter stops at 15, and near the root that happens within the
+            // first rounds of a frame, so each lane remembers which words of its current path it has seen saturated
+            // (satm: set by the walk, which reads every word from level K+1 down anyway; a restart at level r keeps the
+            // bits of the levels above r; and the workgroup's table of saturated words, see the queue above) and only
+            // reports the others.  Nothing is loaded here: the words of levels 1..K, which the walk never reads (the top
+            // table stands for them), are reported until the table knows them -- a compare-and-swap that finds a 15 does nothing.
+            // Final counters = min(15, old + visits), like the RESTART kernel.
+            // (Wave-uniform control flow around per-lane predicates: the queue cursor is a scalar.)
+            const bool at_leaf = (st ^ ST_DESC) >= (ST_ACTIVE | ST_DESC);
+            const uint64_t c_c0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
+            if (__ballot(at_leaf) != 0ull) {
+                const uint32_t L = (st >> ST_L_SHIFT) & 31u;
+                uint32_t todo = at_leaf ? (~satm & ((1u << L) - 2u)) : 0u;  // levels 1 .. L-1 not known to be saturated
+                while (__ballot(todo != 0u) != 0ull) {
+                    bool mine = todo != 0u;
+                    const uint32_t l = mine ? (uint32_t)__builtin_ctz(todo) : 1u;
+                    todo &= todo - 1u;
+                    if (DBG && lane == 0u) dbg_desc_iters += 1u;  // (CNT: slot 12 = iterations of this loop)
                     const uint32_t kk = l - 1u, shc = (uint32_t)D - kk;
                     uint32_t g = 0u;
                     if (l >= (uint32_t)SBASE) {
@@ -1097,15 +1165,20 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                     }
                     const uint32_t bit = (uint32_t)D - l;
                     const uint32_t p = g + ((((uint32_t)ix >> bit) & 1u) << 2 | (((uint32_t)iy >> bit) & 1u) << 1 | (((uint32_t)iz >> bit) & 1u));
-                    const uint32_t word = load_word(rs, p);
-                    if ((word & 15u) == 15u && l == sat + 1u) sat = l;
-                    count_visit(a.count_nodes, a.n_words, p, word);
+                    if (mine && sat_tags[sat_slot(p)] == p) {  // some lane of the workgroup has seen it reach 15
+                        satm |= 1u << l;
+                        mine = false;
+                    }
+                    cq_push(mine, p, 0u);
                 }
-                // the leaf itself: word and address are at hand (a restart leaves sat below the new leaf's level)
-                if ((leaf_w & 15u) == 15u && L == sat + 1u) sat = L;
-                count_visit(a.count_nodes, a.n_words, leaf_off >> 2, leaf_w);
-                st = (st & ~(31u << ST_SAT_SHIFT)) | (sat << ST_SAT_SHIFT);
+                // the leaf itself: word and address are at hand
+                cq_push(at_leaf && sat_tags[sat_slot(leaf_off >> 2)] != (leaf_off >> 2), leaf_off >> 2, leaf_w);
             }
+            if (DBG) dbg_desc_start += (uint32_t)(__builtin_amdgcn_s_memtime() - c_c0);  // (CNT: slot 15 = cycles spent counting)
+        }
+        // ---- 3. hit test / DDA step (shader.wgsl:215-244), clean rays, grid units ----
+        if ((st ^ ST_DESC) >= (ST_ACTIVE | ST_DESC)) {  // ST_ACTIVE and not ST_DESC: at a leaf (rays picked up above descend first)
+            const uint32_t L = (st >> ST_L_SHIFT) & 31u;
             const bool too_deep = leaf_w < (kVoxelOffset << 4);  // descent stopped on an interior word
             const bool solid = (leaf_w >> 4) != kVoxelOffset;
             // leaf centre in grid units straight from the path code: keep the top L bits, set the next one
@@ -1172,14 +1245,14 @@ __global__ __launch_bounds__(BLOCK, 6) void trace_stack_kernel(TraceArgs a, uint
                 st |= ST_DESC;
                 const uint32_t r = min(min(c + 1u, L), (uint32_t)SMAX);
                 if (CNT) {  // levels r and below belong to a new path
-                    const uint32_t sat = min((st >> ST_SAT_SHIFT) & 31u, r - 1u);
-                    st = (st & ~(31u << ST_SAT_SHIFT)) | (sat << ST_SAT_SHIFT);
+                    satm &= (1u << r) - 1u;
                 }
                 restart_at(r);
             }
         }
         if (DBG) c_step += (uint32_t)(__builtin_amdgcn_s_memtime() - c_mark);
     }
+    if (CNT) cq_flush();
     if (DBG) {  // wave totals of the per-lane tallies
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -1655,13 +1728,14 @@ static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipS
                                         : (pairs ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, true, true>
                                                  : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, true, false>))
                     : (args.count_nodes
-                           ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, false, false>
+                           ? (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, true, false, false>
+                                         : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, false, false>)
                            : (args.debug ? (pairs ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false, true>
                                                   : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false, false>)
                                          : (pairs ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false, true>
                                                   : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false, false>)));
     size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
-                                0) * sizeof(uint32_t);
+                                (args.count_nodes ? (kStackBlock / 64) * kCountQueue + kSatTags : 0)) * sizeof(uint32_t);
     // cached per context (= per device): [deep stack?][fused shadows?][counting instantiation?]
     int &blocks_per_cu = li.occupancy[(pairs ? 8 : 0) + (NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
     if (blocks_per_cu == 0) {

@@ -14,6 +14,7 @@ import __graft_entry__ as entry  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--res", default="1920x1080")
+ap.add_argument("--census", action="store_true")
 a = ap.parse_args()
 pkg = entry.load_package()
 cam, look = pkg.scenes.terrain_camera(0, 16)
@@ -43,6 +44,34 @@ def run(clear, flags):
     return float(np.median(ms)), float(min(ms))
 
 
+def census():
+    """What one frame from cleared counters leaves behind: how many words were touched, and how many increments that took."""
+    render.set_flags(pause_adaptive=False, shadows=False)
+    render.update(pkg.Settings(), pkg.Character(cam, look))
+    compute.update(int(words.size)); compute.read_lists()
+    render.render(hits=hits); gpu.sync()
+    w = render.read_nodes()
+    c = (w & 15).astype(np.int64)
+    leaf = (w >> 4) >= (1 << 27)
+    steps = (hits[:, 2] & 0xFF).sum().item()
+    print(f"census: {int((c > 0).sum()):,} of {w.size:,} words touched ({int((leaf & (c > 0)).sum()):,} leaves), sum of counters "
+          f"{int(c.sum()):,} (leaves {int(c[leaf].sum()):,}), saturated {int((c == 15).sum()):,} (leaves {int((leaf & (c == 15)).sum()):,}); "
+          f"ray steps {steps:,}", flush=True)
+    print("  counter histogram, leaves:  ", np.bincount(c[leaf], minlength=16).tolist())
+    print("  counter histogram, interior:", np.bincount(c[~leaf], minlength=16).tolist(), flush=True)
+    import ctypes
+    from importlib import import_module
+    L = pkg._lib.lib()
+    if hasattr(L, "svo_debug_cnt_stats"):
+        buf = (ctypes.c_ulonglong * 8)()
+        L.svo_debug_cnt_stats(buf)
+        print("  atomics: attempts", buf[0], "failures", buf[1], "first failure found the word saturated", buf[2], flush=True)
+    compute.update(int(words.size)); compute.read_lists()
+
+
+if "--census" in sys.argv:
+    census()
+    sys.exit(0)
 for name, clear, flags in (("static (counters paused)", False, dict(pause_adaptive=True, shadows=False)),
                            ("counters live, cleared before every frame", True, dict(pause_adaptive=False, shadows=False)),
                            ("counters live, carried over", False, dict(pause_adaptive=False, shadows=False))):

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--w", type=int, default=1920)
     ap.add_argument("--h", type=int, default=1080)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--count", action="store_true", help="hit counters live, cleared before the frame (the reference's default mode)")
     ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE for gpu.set_option (e.g. REFILL_MIN=8)")
     a = ap.parse_args()
     pkg = entry.load_package()
@@ -39,7 +40,14 @@ def main():
         raise SystemExit("unknown scene")
     gpu = pkg.Gpu(0)
     render = pkg.Render(gpu, (W, H), words, capacity=words.size)
-    render.set_flags(pause_adaptive=True, shadows=False)
+    render.set_flags(pause_adaptive=not a.count, shadows=False)
+    compute = pkg.Compute.new(gpu, render) if a.count else None
+    if a.count:
+        gpu.set_option(pkg.gpu.OPT_SCAN_CLEARS_COUNTERS, 1)
+
+    def clear():
+        if a.count:
+            compute.update(int(words.size)); compute.read_lists()
     render.update(pkg.Settings(), pkg.Character(*pose))
     for o in a.opt:
         k, v = o.split("=")
@@ -48,9 +56,11 @@ def main():
     hits = render.alloc_hits(W * H)
     gpu.set_option(pkg.gpu.OPT_TIMING, 8)
     for _ in range(4):
+        clear()
         render.render(hits=hits)
     ms_plain = gpu.last_render_ms()
     gpu.sync()
+    clear()
     gpu.set_option(pkg.gpu.OPT_DEBUG_BUFFER, dbg.data_ptr())
     render.render(hits=hits)
     ms = gpu.last_render_ms()
@@ -81,6 +91,8 @@ def main():
                             "step": int(d[:, 10].mean()), "sum": int(life_cyc.mean())},
         "cycles_per_round": {"refill_incl_gen": round(float(d[:, 8].sum() / max(rounds, 1)), 1), "gen": round(float(d[:, 11].sum() / max(rounds, 1)), 1),
                              "descent": round(float(d[:, 9].sum() / max(rounds, 1)), 1), "step": round(float(d[:, 10].sum() / max(rounds, 1)), 1)},
+        "counting": {"cycles_per_round": round(float(d[:, 15].sum() / max(rounds, 1)), 1), "level_loop_iters_per_round": round(float(d[:, 12].sum() / max(rounds, 1)), 2),
+                     "flush_cycles_per_round": round(float(d[:, 13].sum() / max(rounds, 1)), 1), "cycles_per_flush": round(float(d[:, 13].sum() / max(d[:, 14].sum(), 1)), 1), "flushes_per_wave": round(float(d[:, 14].mean()), 2)} if a.count else None,
         "cycles_per_generated_strip": round(float(d[:, 11].sum() / max(d[:, 7].sum(), 1)), 1),
         "shader_clock_ghz_in_kernel": round(float(np.median(life_cyc / np.maximum((d[:, 2] - d[:, 0]) * 10.0, 1))), 3),
         # descent shape: wave-level iterations (dependent loads) per round vs the mean over lanes
