@@ -317,8 +317,11 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
 // descending from the root: depth-20 fractal -24 % at 1080p) and large frames (depth-16 terrain: -8 % at 4K, but +5 % at
 // 1080p, where one lane's primary-plus-shadow chain lengthens the frame's tail more than the second launch costs).
 bool fuse_shadow_rays(const svo_ctx *ctx, size_t n_pixels) {
+    // (and with live hit counters: one launch shares the visit queue's start-up and the workgroup's table of saturated words
+    // between a primary ray and its shadow ray -- default mode 1.58 -> 1.47 ms at 1080p)
+    const bool counting = !(ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE);
     const bool want = ctx->fused_shadows == 1 ||
-                      (ctx->fused_shadows == 2 && (ctx->tree_depth > (uint32_t)svo::stack_max_depth(false) || n_pixels >= (1u << 22)));
+                      (ctx->fused_shadows == 2 && (ctx->tree_depth > (uint32_t)svo::stack_max_depth(false) || n_pixels >= (1u << 22) || counting));
     if (!want || ctx->variant != SVO_VARIANT_STACK || ctx->tree_depth > (uint32_t)svo::stack_max_depth(true)) return false;
     const float *sd = ctx->uniforms.sun_dir;
     const float sl = sqrtf((sd[0] * sd[0] + sd[1] * sd[1]) + sd[2] * sd[2]);

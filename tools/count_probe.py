@@ -59,13 +59,6 @@ def census():
           f"ray steps {steps:,}", flush=True)
     print("  counter histogram, leaves:  ", np.bincount(c[leaf], minlength=16).tolist())
     print("  counter histogram, interior:", np.bincount(c[~leaf], minlength=16).tolist(), flush=True)
-    import ctypes
-    from importlib import import_module
-    L = pkg._lib.lib()
-    if hasattr(L, "svo_debug_cnt_stats"):
-        buf = (ctypes.c_ulonglong * 8)()
-        L.svo_debug_cnt_stats(buf)
-        print("  atomics: attempts", buf[0], "failures", buf[1], "first failure found the word saturated", buf[2], flush=True)
     compute.update(int(words.size)); compute.read_lists()
 
 

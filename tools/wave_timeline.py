@@ -92,7 +92,7 @@ def main():
         "cycles_per_round": {"refill_incl_gen": round(float(d[:, 8].sum() / max(rounds, 1)), 1), "gen": round(float(d[:, 11].sum() / max(rounds, 1)), 1),
                              "descent": round(float(d[:, 9].sum() / max(rounds, 1)), 1), "step": round(float(d[:, 10].sum() / max(rounds, 1)), 1)},
         "counting": {"cycles_per_round": round(float(d[:, 15].sum() / max(rounds, 1)), 1), "level_loop_iters_per_round": round(float(d[:, 12].sum() / max(rounds, 1)), 2),
-                     "flush_cycles_per_round": round(float(d[:, 13].sum() / max(rounds, 1)), 1), "cycles_per_flush": round(float(d[:, 13].sum() / max(d[:, 14].sum(), 1)), 1), "flushes_per_wave": round(float(d[:, 14].mean()), 2)} if a.count else None,
+                     "flush_cycles_per_round": round(float(d[:, 13].sum() / max(rounds, 1)), 1), "flushes_per_wave": round(float(d[:, 14].mean()), 2)} if a.count else None,
         "cycles_per_generated_strip": round(float(d[:, 11].sum() / max(d[:, 7].sum(), 1)), 1),
         "shader_clock_ghz_in_kernel": round(float(np.median(life_cyc / np.maximum((d[:, 2] - d[:, 0]) * 10.0, 1))), 3),
         # descent shape: wave-level iterations (dependent loads) per round vs the mean over lanes
