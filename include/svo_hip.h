@@ -123,6 +123,12 @@ typedef enum svo_option {
     SVO_OPT_CAMERA_SHORTCUT = 15, /* pixel frames, camera inside the cube, STACK variant: every primary ray starts in the camera's leaf, so a wave
                                 walks from the root to it once and its lanes copy that walk when they pick up a ray.  1 (default) on, 0 off.
                                 Results do not depend on it. */
+    SVO_OPT_SCHEDULE_MOTION = 16, /* strip schedule while the camera moves (pixel frames of one rectangle): strips that had at least
+                                `min_count` strips with a step-limit ray among their (2 radius + 1)^2 neighbours are scheduled as at least
+                                class `floor`.  value = floor (1..12; 0 = off) | radius << 8 | min_count << 12; default 0x1204 (at least class 4
+                                for strips with one such strip among their 24 neighbours: 3 - 5 % off a moving camera's frame).  When the
+                                camera comes to rest the lists are rebuilt once more from the classes as measured.
+                                Results do not depend on it. */
     SVO_OPT_PRIO_STEPS = 6   /* accepted and ignored: raising the issue priority of waves with old rays measured no effect and
                                 left the kernel */
 } svo_option;

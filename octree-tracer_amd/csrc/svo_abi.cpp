@@ -292,10 +292,17 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         // frames is a backstop for node buffers written behind this context's back).
         const bool same_input = (wd.mode != 2 || opt.sched_slot == 1) && sc.built_nodes_version == ctx->store->version &&
                                 memcmp(&sc.built_uniforms, &ctx->uniforms, sizeof(svo_uniforms)) == 0 && sc.age < 64;
-        const bool rebuild = schedule && (!sc.valid || (sc.order_filtered && !filtered) || (!same_input && sc.age + 1 >= ctx->sched_period));
+        const bool moving = sc.have_prev && memcmp(&sc.prev_uniforms, &ctx->uniforms, sizeof(svo_uniforms)) != 0;
+        const bool rebuild = schedule && (!sc.valid || (sc.order_filtered && !filtered) || (!same_input && sc.age + 1 >= ctx->sched_period) ||
+                                          (same_input && sc.floored && !moving));
+        // a camera in motion: strips near the long ones of this frame are not scheduled as cheap (strip_danger_kernel)
+        const bool floor_now = rebuild && !filtered && moving && ctx->motion_floor != 0u && wd.mode == 0 && wd.n_rects == 1u;
         // (a launch with a skip mask builds its lists before the trace, every frame: here only the costs are measured)
         HIP_TRY(ctx, svo::launch_post(a, li, rebuild ? sc.cost : nullptr, sc.order, n_strips, (n_strips + 7u) / 8u + 16u,
-                                      rebuild && !filtered, ctx->stream));
+                                      rebuild && !filtered, ctx->stream, floor_now ? sc.cls_now : nullptr, ctx->motion_floor));
+        if (rebuild && !filtered) sc.floored = floor_now;
+        sc.prev_uniforms = ctx->uniforms;
+        sc.have_prev = true;
         ctx->frame_parity ^= 1;
         if (rebuild) {
             if (!filtered) sc.order_filtered = false;  // the post pass has just built complete lists
@@ -671,6 +678,11 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
         case SVO_OPT_TREE_DEPTH:
             if (value < 1 || value > 31) return fail(ctx, SVO_ERR_ARG, "tree depth must be 1..31");
             ctx->tree_depth = (uint32_t)value;  // (which kernel that means is decided per launch, see trace_launch)
+            return SVO_OK;
+        case SVO_OPT_SCHEDULE_MOTION:
+            if (value < 0 || (value & 15) > 12 || ((value >> 8) & 15) > 4 || (value >> 12) > 80)
+                return fail(ctx, SVO_ERR_ARG, "schedule motion: class floor (0..12, 0 = off) | radius (0..4) << 8 | min_count (0..80) << 12");
+            ctx->motion_floor = (uint32_t)value;
             return SVO_OK;
         case SVO_OPT_CAMERA_SHORTCUT:
             ctx->cam_shortcut = value != 0;

@@ -86,8 +86,14 @@ struct svo_ctx {
         // what the schedule was measured on: while camera and tree stay the same it stays exact and is not rebuilt
         svo_uniforms built_uniforms{};
         uint64_t built_nodes_version = 0;
+        // camera motion (SVO_OPT_SCHEDULE_MOTION): the uniforms of the previous frame, and whether the lists in `order` were
+        // built with the floor for strips near long ones (then they are rebuilt once more, exactly, when the camera rests)
+        svo_uniforms prev_uniforms{};
+        bool have_prev = false;
+        bool floored = false;
     };
     Sched sched[2];
+    uint32_t motion_floor = 0x1204;  // SVO_OPT_SCHEDULE_MOTION: class floor | radius << 8 | min_count << 12; 0 = off
     bool schedule = true;
     uint32_t sched_period = 2;  // frames between schedule rebuilds (tools/perf_probe.py --motion: 2 keeps the gain under camera motion)
     int frame_parity = 0;

@@ -82,7 +82,7 @@ int stack_max_depth(bool deep);
 constexpr uint32_t kMaxScheduledStrips = 1u << 20;  // (2^26 items / 64)
 constexpr uint32_t kOrderHistWords = 64 * 16;      // chunk histograms of the schedule builder, stored behind the class bytes
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
-                       uint32_t cap, bool build_schedule, hipStream_t stream);
+                       uint32_t cap, bool build_schedule, hipStream_t stream, uint8_t *moved = nullptr, uint32_t motion_floor = 0);
 
 // explicit rays with a skip mask: this frame's strip lists without the strips that hold no ray (classes from `prev`, or screen order)
 hipError_t launch_schedule_skipping(const uint8_t *skip, uint32_t n_items, const uint8_t *prev, uint8_t *cls, uint32_t *sched,

@@ -1901,8 +1901,34 @@ hipError_t launch_schedule_skipping(const uint8_t *skip, uint32_t n_items, const
 
 // After the STACK kernel: deferred rays, per-strip cost classes (cost != nullptr), counter re-arm; and, when
 // `build_schedule`, the strip lists for the next frames.
+// Cost classes for a camera that MOVES.  The strips that decide a frame hold a ray that runs into the step limit; those rays
+// are isolated pixels, and which pixels they are changes with a sub-pixel change of the view: the class a strip
+// had one frame ago says little about whether it holds one now.  Where they can be does carry over -- they come in regions
+// (grazing views of the terrain), other regions (sky, near surfaces seen head-on) have none.  A strip with at least
+// `min_count` such strips among its (2 radius + 1)^2 neighbours is therefore given at least class `floor_class`: "cheap, but
+// one in ten of its kind turns out to take the whole frame" sorts before "cheap" without getting ahead of the strips that
+// were measured long.
+__global__ __launch_bounds__(256) void strip_danger_kernel(const uint8_t *in, uint8_t *out, uint32_t n_strips, uint32_t bpr, int radius,
+                                                           uint32_t min_count, uint32_t floor_class) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= n_strips) return;
+    const int by = (int)(s / bpr), bx = (int)(s - (uint32_t)by * bpr), rows = (int)((n_strips + bpr - 1u) / bpr);
+    uint32_t c = in[s], near = 0u;
+    if (c < floor_class) {
+        for (int dy = -radius; dy <= radius; dy++)
+            for (int dx = -radius; dx <= radius; dx++) {
+                const int y = by + dy, x = bx + dx;
+                if (y < 0 || y >= rows || x < 0 || x >= (int)bpr) continue;
+                const uint32_t t = (uint32_t)y * bpr + (uint32_t)x;
+                if (t < n_strips && in[t] >= 8u) near++;
+            }
+        if (near >= min_count) c = floor_class;
+    }
+    out[s] = (uint8_t)c;
+}
+
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
-                       uint32_t cap, bool build_schedule, hipStream_t stream) {
+                       uint32_t cap, bool build_schedule, hipStream_t stream, uint8_t *moved, uint32_t motion_floor) {
     // without the cost pass the launch only re-arms counters and traces deferred rays: normally none, but a frame
     // full of them (every ray NaN / extreme) must not crawl through 16 workgroups
     uint32_t blocks = cost ? (n_strips + 3u) / 4u : 256u;
@@ -1911,10 +1937,16 @@ hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cos
     hipLaunchKernelGGL(post_kernel, dim3(blocks), dim3(256), 0, stream, args, li.counters, (const uint32_t *)li.defer,
                        li.next_defer_count, cost, n_strips);
     if (cost && build_schedule) {
+        const uint8_t *cls = cost;
+        if (moved && motion_floor) {  // (pixel frames of one rectangle: the ABI passes `moved` only then)
+            hipLaunchKernelGGL(strip_danger_kernel, dim3((n_strips + 255u) / 256u), dim3(256), 0, stream, (const uint8_t *)cost, moved, n_strips,
+                               args.work.bpr, (int)((motion_floor >> 8) & 15u), (motion_floor >> 12) & 255u, motion_floor & 15u);
+            cls = moved;
+        }
         // the chunk histograms live behind the class bytes (the ABI allocates kOrderHistWords extra words)
-        uint32_t *hist = reinterpret_cast<uint32_t *>(cost + ((n_strips + 15u) & ~15u));
-        hipLaunchKernelGGL(strip_hist_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, (const uint8_t *)cost, n_strips, hist);
-        hipLaunchKernelGGL(strip_order_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, (const uint8_t *)cost,
+        uint32_t *hist = reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(cls) + ((n_strips + 15u) & ~15u));
+        hipLaunchKernelGGL(strip_hist_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, cls, n_strips, hist);
+        hipLaunchKernelGGL(strip_order_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, cls,
                            (const uint32_t *)hist, sched, n_strips, cap);
     }
     return hipGetLastError();

@@ -17,6 +17,7 @@ ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--period", default="1,2")
 ap.add_argument("--pairs", action="store_true")
 ap.add_argument("--classes", action="store_true", help="how well do a frame's strip cost classes predict the next frame's?")
+ap.add_argument("--floor", default="0", help="SVO_OPT_SCHEDULE_MOTION values to compare (continuous mode), e.g. 0,0x2205")
 ap.add_argument("--hold", action="store_true", help="exact schedule held while another pose is traced in between: schedule or caches?")
 a = ap.parse_args()
 pkg = entry.load_package()
@@ -94,13 +95,14 @@ elif a.pairs:
                 ta.append(t1); tb.append(t2)
         print(f"yaw {deg} deg/step: stale schedule {np.median(ta):.4f} ms, exact schedule {np.median(tb):.4f} ms (kernel, median of {a.steps})", flush=True)
 else:
-    for kind, period, deg in itertools.product(["yaw", "yaw+pitch", "walk"], [int(x) for x in a.period.split(",")],
-                                               [float(x) for x in a.deg.split(",")]):
+    for kind, period, deg, fl in itertools.product(["yaw", "yaw+pitch", "walk"], [int(x) for x in a.period.split(",")],
+                                                   [float(x) for x in a.deg.split(",")], [int(x, 0) for x in a.floor.split(",")]):
         gpu.set_option(pkg.gpu.OPT_SCHEDULE, period)
+        gpu.set_option(pkg.gpu.OPT_SCHEDULE_MOTION, fl)
         ts = []
         for i in range(a.steps + 4):
             render.update(pkg.Settings(), pkg.Character(*pose(kind, deg, i)))
             render.render(hits=hits); gpu.sync()
             if i >= 4:
                 ts.append(gpu.last_render_ms())
-        print(f"{kind} {deg}/step, schedule period {period}: {np.median(ts):.4f} ms kernel (median of {a.steps} frames)", flush=True)
+        print(f"{kind} {deg}/step, schedule period {period}, motion floor {fl:#x}: {np.median(ts):.4f} ms kernel (median of {a.steps} frames)", flush=True)
