@@ -14,7 +14,7 @@ constexpr int kTopLevels = 3;                  // K: octree levels folded into t
 constexpr int kTopEntries = 1 << (3 * kTopLevels);
 constexpr int kTopAuxEntries = 8 + 64;  // level-1 and level-2 cells -> child group of the next level (kTopLevels = 3)
 constexpr int kPathBits = 24;                  // D: integer path-code bits per axis
-constexpr int kCounterWords = 256;             // 8 claim counters, one per 128-byte line
+constexpr int kCounterWords = 2048;            // 64 claim counters (8 lists x 8 counters), one per 128-byte line
 
 // Top-table entry (one per level-K cell, index = cx << 2K | cy << K | cz): level << 27 | child group index.
 // The level is K+1 below an interior cell, or the shallower level at which a leaf covers the whole cell

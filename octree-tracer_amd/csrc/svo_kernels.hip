@@ -490,6 +490,43 @@ __device__ __forceinline__ ItemFast decode_item_fast(const WorkDesc &w, uint32_t
     return it;
 }
 
+// The same for the 64 items of one block, lane by lane: `first` is the item of lane 0 -- a multiple of 64 and the same on every
+// lane, so the block's row, column and rectangle are found once per wave on the scalar unit (three divisions by
+// multiplication: ~80 vector instructions per generated strip when done per lane) and only the position inside the block
+// is per-lane work.
+__device__ __forceinline__ ItemFast decode_item_wave(const WorkDesc &w, uint32_t first, uint32_t lane) {
+    ItemFast it;
+    const uint32_t q = first + lane;
+    if (w.mode == 2) {
+        it.valid = q < w.n_items;
+        it.out = q;
+        it.px = it.py = 0;
+        return it;
+    }
+    const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 6));
+    uint32_t rect = 0, b = blk;
+    if (w.n_rects > 1u) {
+        rect = fast_div(blk, w.bprect, w.magic_bprect);
+        b = blk - rect * w.bprect;
+    }
+    const uint32_t by = fast_div(b, w.bpr, w.magic_bpr), bx = b - by * w.bpr;
+    uint32_t ox = w.x0, oy = w.y0;
+    if (w.mode == 1) {
+        const uint32_t t = w.first_tile + rect * w.tile_stride;
+        const uint32_t ty = fast_div(t, w.tiles_x, w.magic_tiles_x);
+        ox = (t - ty * w.tiles_x) * w.w;
+        oy = ty * w.h;
+    }
+    const uint32_t x0 = bx << w.bw_log2, y0 = by << (6u - w.bw_log2), out0 = rect * (w.w * w.h) + y0 * w.w + x0;  // (scalar)
+    const uint32_t lx = lane & ((1u << w.bw_log2) - 1u), ly = lane >> w.bw_log2;
+    const uint32_t x = x0 + lx, y = y0 + ly;
+    it.valid = (q < w.n_items) && (x < w.w) && (y < w.h);
+    it.out = out0 + ly * w.w + lx;
+    it.px = ox + x;
+    it.py = oy + y;
+    return it;
+}
+
 // a / d given y = RN(1 / d):  q0 = a*y,  r = a - d*q0 (exact, one fma),  q0 + r*y rounded once -- the same bits as
 // IEEE a / d.  Markstein's theorem gives this for a faithful q0; that q0 = RN(a*y) is always good enough is
 // established exhaustively: tools/divtest_gpu.hip compares the sequence with a / d for all 2^23 x 2^23 pairs
@@ -660,6 +697,15 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
     // order -- and moves on to the next region when its own is exhausted (work stealing keeps the tail short;
     // a single counter would serialise at ~88 claims/us).  Static mode: strips dealt round-robin to waves.
     constexpr uint32_t kShards = 8, kShardStride = 32;  // counters 128 B apart
+    // Every list has kSubs claim counters, each handing out every kSubs-th of the list's entries (counter j: entries
+    // reserved + j, reserved + j + kSubs, ...: every counter walks the whole list, longest strips first); a workgroup
+    // uses counter (blockIdx / kShards) % kSubs of its list and tries the list's other counters before it moves on to
+    // the next list.  Atomics are executed at the memory side, one address at a time (11 ns each): on a frame of short
+    // rays the waves finish their strips in step, 768 claims arrive at one counter together, and the last of them
+    // waited 8 us -- half of such a frame was spent waiting for claims (wave_timeline: 90 k of 187 k cycles per wave on
+    // config 2).
+    constexpr uint32_t kSubs = 8;
+    const uint32_t my_sub = (blockIdx.x / kShards) % kSubs;
     const uint32_t n_strips = (n_items + strip_items - 1) / strip_items;
     const uint32_t per_shard = (n_strips + kShards - 1) / kShards;
     // a.order (optional): strip numbers sorted by the cost they had in the previous frame, longest rays first
@@ -676,22 +722,39 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
     auto claim = [=](Cursor c, bool first) -> Cursor {
         uint32_t s = 0xFFFFFFFFu;
         if (work_counter) {
-            while (c.shard_try < kShards) {
-                const uint32_t sh = (blockIdx.x + c.shard_try) % kShards;
-                const uint32_t reserved = ((gridDim.x + kShards - 1u - sh) / kShards) * (uint32_t)(BLOCK / 64);
-                uint32_t k = my_rank;
-                if (!first) {
-                    if (lane == 0) k = atomicAdd(work_counter + sh * kShardStride, 1u);
-                    k = __builtin_amdgcn_readfirstlane(k) + reserved;
-                }
-                first = false;
+            if (first) {  // the reserved entry of this wave on its home list
+                const uint32_t sh = blockIdx.x % kShards;
                 if (order) {
-                    if (k < order[sh]) { s = order[kShards + sh * a.order_cap + k]; break; }
+                    if (my_rank < order[sh]) s = order[kShards + sh * a.order_cap + my_rank];
+                } else {
+                    const uint32_t cand = sh * per_shard + my_rank;
+                    if (my_rank < per_shard && cand < n_strips) s = cand;
+                }
+                if (s == 0xFFFFFFFFu) c.shard_try = 1u;  // (more waves than entries: look elsewhere)
+            }
+            // Away from the home counter (it ran out): lane i looks at counter i -- one load for all 64 -- and the wave draws from
+            // the first counter that still has entries, starting with the other counters of its own list, then list by list.
+            // (Probing them one atomic after the other would cost a finished wave 64 round trips to find out that the frame is over.)
+            while (s == 0xFFFFFFFFu && c.shard_try != 0u) {
+                const uint32_t l = lane / kSubs, sb = lane % kSubs;
+                const uint32_t cv = __hip_atomic_load(work_counter + lane * kShardStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t res_l = ((gridDim.x + kShards - 1u - l) / kShards) * (uint32_t)(BLOCK / 64);
+                const uint32_t len_l = order ? order[l] : min(per_shard, n_strips - min(n_strips, l * per_shard));
+                const uint64_t has = __ballot((uint64_t)cv * kSubs + sb + res_l < (uint64_t)len_l);
+                if (!has) break;
+                const uint32_t start = (blockIdx.x % kShards) * kSubs + my_sub;
+                const uint64_t rot = start ? ((has >> start) | (has << (64u - start))) : has;
+                const uint32_t pick = (start + (uint32_t)__ffsll((unsigned long long)rot) - 1u) & 63u;
+                const uint32_t sh = pick / kSubs, sub = pick % kSubs;
+                uint32_t k = 0u;
+                if (lane == 0) k = atomicAdd(work_counter + pick * kShardStride, 1u);
+                k = __builtin_amdgcn_readfirstlane(k) * kSubs + sub + ((gridDim.x + kShards - 1u - sh) / kShards) * (uint32_t)(BLOCK / 64);
+                if (order) {
+                    if (k < order[sh]) s = order[kShards + sh * a.order_cap + k];
                 } else {
                     const uint32_t cand = sh * per_shard + k;
-                    if (k < per_shard && cand < n_strips) { s = cand; break; }
+                    if (k < per_shard && cand < n_strips) s = cand;
                 }
-                c.shard_try += 1;
             }
         } else {
             if (c.strip < n_strips) s = c.strip;
@@ -972,7 +1035,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
             if (pending && pool_n == 0u) {  // now the answer of the early claim is needed
                 pending = false;
                 const uint32_t sh = blockIdx.x % kShards;
-                const uint32_t k = __builtin_amdgcn_readfirstlane(pend) + ((gridDim.x + kShards - 1u - sh) / kShards) * (uint32_t)(BLOCK / 64);
+                const uint32_t k = __builtin_amdgcn_readfirstlane(pend) * kSubs + my_sub + ((gridDim.x + kShards - 1u - sh) / kShards) * (uint32_t)(BLOCK / 64);
                 uint32_t s = 0xFFFFFFFFu;
                 if (order) {
                     if (k < order[sh]) s = order[kShards + sh * a.order_cap + k];
@@ -1003,7 +1066,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                     float gp0 = 0, gp1 = 0, gp2 = 0, gd0 = 1, gd1 = 1, gd2 = 1, gdist = 0;
                     uint32_t gout = 0;
                     if (q < strip_end) {
-                        ItemFast it = decode_item_fast(a.work, q);
+                        ItemFast it = decode_item_wave(a.work, next, lane);
                         if (a.work.mode == 2 && a.skip && a.skip[q]) it.valid = false;  // no ray: the producer wrote the record
                         if (it.valid) {
                             RayIn r;
@@ -1057,7 +1120,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                     next += min(64u, strip_end - next);
                     if (next >= strip_end) {
                         if (work_counter && cur.shard_try == 0u) {
-                            if (lane == 0) pend = atomicAdd(work_counter + (blockIdx.x % kShards) * kShardStride, 1u);
+                            if (lane == 0) pend = atomicAdd(work_counter + ((blockIdx.x % kShards) * kSubs + my_sub) * kShardStride, 1u);
                             pending = true;
                             next = strip_end = 0xFFFFFFFEu;  // not known yet (and not "dry")
                         } else {
@@ -1434,7 +1497,7 @@ __global__ __launch_bounds__(256) void post_kernel(TraceArgs a, uint32_t *claim_
         const uint32_t lane = threadIdx.x & 63u;
         const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = gridDim.x * 4u;
         for (uint32_t s = wave; s < n_strips; s += n_waves) {
-            ItemFast it = decode_item_fast(a.work, s * 64u + lane);
+            ItemFast it = decode_item_wave(a.work, s * 64u, lane);
             uint32_t steps = 0;
             if (it.valid) {
                 steps = reinterpret_cast<const uint4 *>(a.hits)[it.out].z & 0xFFu;
@@ -1737,7 +1800,7 @@ static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipS
     size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
                                 (args.count_nodes ? (kStackBlock / 64) * kCountQueue + kSatTags : 0)) * sizeof(uint32_t);
     // cached per context (= per device): [deep stack?][fused shadows?][counting instantiation?]
-    int &blocks_per_cu = li.occupancy[(pairs ? 8 : 0) + (NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
+    int &blocks_per_cu = li.occupancy[(args.debug ? 16 : 0) + (pairs ? 8 : 0) + (NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
     if (blocks_per_cu == 0) {
         int n = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kStackBlock, lds_bytes);
@@ -1821,7 +1884,7 @@ __global__ __launch_bounds__(256) void strip_cull_kernel(TraceArgs a, const uint
     mat_vec(a.u.camera_inverse, 0.0f, 0.0f, 0.0f, 1.0f, p4);
     const float o0 = p4[0] / p4[3], o1 = p4[1] / p4[3], o2 = p4[2] / p4[3];
     for (uint32_t s = wave; s < n_strips; s += n_waves) {
-        const ItemFast it = decode_item_fast(a.work, s * 64u + lane);
+        const ItemFast it = decode_item_wave(a.work, s * 64u, lane);
         // pixel bounds of the strip's valid pixels
         uint32_t x_lo = it.valid ? it.px : 0xFFFFFFFFu, x_hi = it.valid ? it.px : 0u, y_lo = it.valid ? it.py : 0xFFFFFFFFu, y_hi = it.valid ? it.py : 0u;
 #pragma unroll
