@@ -705,6 +705,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
     // waited 8 us -- half of such a frame was spent waiting for claims (wave_timeline: 90 k of 187 k cycles per wave on
     // config 2).
     constexpr uint32_t kSubs = 8;
+    static_assert(kShards * kSubs == 64, "the stealing probe reads one counter per lane");
     const uint32_t my_sub = (blockIdx.x / kShards) % kSubs;
     const uint32_t n_strips = (n_items + strip_items - 1) / strip_items;
     const uint32_t per_shard = (n_strips + kShards - 1) / kShards;
