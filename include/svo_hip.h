@@ -96,7 +96,8 @@ typedef enum svo_option {
     SVO_OPT_GRID_BLOCKS = 2, /* persistent grid size override (0 = auto) */
     SVO_OPT_REFILL_MIN = 3,  /* idle lanes needed before a wave refills */
     SVO_OPT_STRIP_ITEMS = 4, /* pixel slots a wave claims at a time (multiple of 64) */
-    SVO_OPT_DYNAMIC_STRIPS = 5, /* 1: waves claim strips from device counters; 0: static round-robin */
+    SVO_OPT_DYNAMIC_STRIPS = 5, /* accepted and ignored: the STACK kernel always claims its strips from device counters (the static
+                                round-robin deal of round 1 cost the hot loop scalar registers) */
     SVO_OPT_SCHEDULE = 8,    /* n > 0 (default 2): trace the strips whose rays took the most steps in an earlier frame of
                                 the same layout first, rebuilding that schedule every n frames; 0: screen order.
                                 Results do not depend on it. */

@@ -269,7 +269,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         ctx->defer_items = want;
     }
     li.counters = ctx->defer_buf;
-    li.work_counter = ctx->dynamic_strips ? ctx->defer_buf : nullptr;
+    li.work_counter = ctx->defer_buf;  // (strips are always claimed dynamically; SVO_OPT_DYNAMIC_STRIPS is accepted and ignored)
     if (ctx->defer_buf) {
         uint32_t *lists = ctx->defer_buf + svo::kCounterWords;
         const size_t stride = ctx->defer_items + 1;

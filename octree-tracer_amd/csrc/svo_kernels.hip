@@ -599,7 +599,7 @@ constexpr int kSatTags = 512;     // CNT: words known to be saturated, direct-ma
 // PAIRS: descend through the pair table, two levels per load (static trees; never together with CNT, which needs the
 // address of every word on the path).
 template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD, bool PAIRS>
-__global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
+__global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
@@ -687,7 +687,6 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
     __syncthreads();
 
     const uint32_t n_items = a.work.n_items;
-    const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + tid) >> 6);
 
     // wave-uniform work cursor: a wave claims strips [next, strip_end) of strip_items items.
@@ -698,84 +697,46 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
     // a single counter would serialise at ~88 claims/us).  Static mode: strips dealt round-robin to waves.
     constexpr uint32_t kShards = 8, kShardStride = 32;  // counters 128 B apart
     // Every list has kSubs claim counters, each handing out every kSubs-th of the list's entries (counter j: entries
-    // reserved + j, reserved + j + kSubs, ...: every counter walks the whole list, longest strips first); a workgroup
-    // uses counter (blockIdx / kShards) % kSubs of its list and tries the list's other counters before it moves on to
-    // the next list.  Atomics are executed at the memory side, one address at a time (11 ns each): on a frame of short
+    // reserved + j, reserved + j + kSubs, ...: every counter walks the whole list, longest strips first); a wave starts
+    // with counter (blockIdx / kShards) % kSubs of its list, takes the list's counters in turn, and moves on to the next
+    // list when they have run out.  Atomics are executed at the memory side, one address at a time (11 ns each): on a frame of short
     // rays the waves finish their strips in step, 768 claims arrive at one counter together, and the last of them
     // waited 8 us -- half of such a frame was spent waiting for claims (wave_timeline: 90 k of 187 k cycles per wave on
     // config 2).
     constexpr uint32_t kSubs = 8;
     static_assert(kShards * kSubs == 64, "the stealing probe reads one counter per lane");
-    const uint32_t my_sub = (blockIdx.x / kShards) % kSubs;
     const uint32_t n_strips = (n_items + strip_items - 1) / strip_items;
-    const uint32_t per_shard = (n_strips + kShards - 1) / kShards;
     // a.order (optional): strip numbers sorted by the cost they had in the previous frame, longest rays first
     // (LPT scheduling: a ray is a serial chain of up to 101 rounds, so the long ones must start early or the
     // whole chip waits for them at the end); layout and rationale at strip_order_kernel.
     const uint32_t *order = a.order;  // 8 list lengths, then 8 lists of a.order_cap strip numbers
-    // (the cursor travels by value: captured by reference it stayed in scratch memory, and a load from scratch
-    // makes everything that depends on it -- the whole refill control flow -- divergent for the compiler)
     // The first entries of every list are RESERVED, one per wave that starts on that list: a wave's first strip is
     // the entry with its own rank, without an atomic (6144 waves claiming at t = 0 queue up for ~10 us on 8
     // counters otherwise); the counters hand out what comes after the reserved part.
-    struct Cursor { uint32_t next, end, strip, shard_try; };
-    const uint32_t my_rank = (blockIdx.x / kShards) * (uint32_t)(BLOCK / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);  // among the waves that start on my list
-    auto claim = [=](Cursor c, bool first) -> Cursor {
-        uint32_t s = 0xFFFFFFFFu;
-        if (work_counter) {
-            if (first) {  // the reserved entry of this wave on its home list
-                const uint32_t sh = blockIdx.x % kShards;
-                if (order) {
-                    if (my_rank < order[sh]) s = order[kShards + sh * a.order_cap + my_rank];
-                } else {
-                    const uint32_t cand = sh * per_shard + my_rank;
-                    if (my_rank < per_shard && cand < n_strips) s = cand;
-                }
-                if (s == 0xFFFFFFFFu) c.shard_try = 1u;  // (more waves than entries: look elsewhere)
-            }
-            // Away from the home counter (it ran out): lane i looks at counter i -- one load for all 64 -- and the wave draws from
-            // the first counter that still has entries, starting with the other counters of its own list, then list by list.
-            // (Probing them one atomic after the other would cost a finished wave 64 round trips to find out that the frame is over.)
-            while (s == 0xFFFFFFFFu && c.shard_try != 0u) {
-                const uint32_t l = lane / kSubs, sb = lane % kSubs;
-                const uint32_t cv = __hip_atomic_load(work_counter + lane * kShardStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t res_l = ((gridDim.x + kShards - 1u - l) / kShards) * (uint32_t)(BLOCK / 64);
-                const uint32_t len_l = order ? order[l] : min(per_shard, n_strips - min(n_strips, l * per_shard));
-                const uint64_t has = __ballot((uint64_t)cv * kSubs + sb + res_l < (uint64_t)len_l);
-                if (!has) break;
-                const uint32_t start = (blockIdx.x % kShards) * kSubs + my_sub;
-                const uint64_t rot = start ? ((has >> start) | (has << (64u - start))) : has;
-                const uint32_t pick = (start + (uint32_t)__ffsll((unsigned long long)rot) - 1u) & 63u;
-                const uint32_t sh = pick / kSubs, sub = pick % kSubs;
-                uint32_t k = 0u;
-                if (lane == 0) k = atomicAdd(work_counter + pick * kShardStride, 1u);
-                k = __builtin_amdgcn_readfirstlane(k) * kSubs + sub + ((gridDim.x + kShards - 1u - sh) / kShards) * (uint32_t)(BLOCK / 64);
-                if (order) {
-                    if (k < order[sh]) s = order[kShards + sh * a.order_cap + k];
-                } else {
-                    const uint32_t cand = sh * per_shard + k;
-                    if (k < per_shard && cand < n_strips) s = cand;
-                }
-            }
-        } else {
-            if (c.strip < n_strips) s = c.strip;
-            c.strip += n_waves;
-        }
-        if (s != 0xFFFFFFFFu) {
-            s = __builtin_amdgcn_readfirstlane(s);
-            c.next = s * strip_items;
-            c.end = min(c.next + strip_items, n_items);
-        } else {
-            c.next = c.end = 0xFFFFFFFFu;
-        }
-        return c;
+    // A claim is issued as soon as a strip has been turned into pool rays, but its answer is only looked at when the pool
+    // is empty again: the atomic's round trip overlaps the traversal instead of stalling the wave.
+    // (Wave-uniform state, kept small -- the kernel sits at the limit of its scalar registers, and what does not fit there
+    // ends up in scratch memory, inside the hot loop: `next` == 0xFFFFFFFE says that a claim is in flight, 0xFFFFFFFF that
+    // the frame has no more strips for this wave.  The stealing code exists once, in the refill step.)
+    uint32_t home = (blockIdx.x % kShards) * kSubs + (blockIdx.x / kShards) % kSubs;  // the claim counter (list * kSubs + counter) this wave draws from
+    uint32_t pend = 0;                // lane 0: what the atomic returned
+    uint32_t next, strip_end;
+    auto entry_of = [=](uint32_t sh, uint32_t k) -> uint32_t {  // strip behind entry k of list sh (0xFFFFFFFF: past the end)
+        if (order) return k < order[sh] ? order[kShards + sh * a.order_cap + k] : 0xFFFFFFFFu;
+        const uint32_t per_shard = (n_strips + kShards - 1) / kShards, cand = sh * per_shard + k;  // no schedule yet: 8 contiguous screen regions
+        return (k < per_shard && cand < n_strips) ? cand : 0xFFFFFFFFu;
     };
-    Cursor cur = claim(Cursor{0u, 0u, wave_id, 0u}, true);
-    // A claim on the home list is issued as soon as a strip has been turned into pool rays, but its answer is only
-    // looked at when the pool is empty again: the atomic's round trip overlaps the traversal instead of stalling the wave.
-    uint32_t pend = 0;      // lane 0: what the atomic returned
-    bool pending = false;   // wave-uniform
-    uint32_t next = cur.next, strip_end = cur.end;
+    {
+        const uint32_t my_rank = (blockIdx.x / kShards) * (uint32_t)(BLOCK / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);  // among the waves that start on my list
+        const uint32_t s0 = __builtin_amdgcn_readfirstlane(entry_of(blockIdx.x % kShards, my_rank));
+        if (s0 != 0xFFFFFFFFu) {
+            next = s0 * strip_items;
+            strip_end = min(next + strip_items, n_items);
+        } else {  // more waves than entries on this list: as if a claim had come back empty (the refill step looks elsewhere)
+            pend = 0x00FFFFFFu;
+            next = strip_end = 0xFFFFFFFEu;
+        }
+    }
     uint32_t pool_n = 0, pool_i = 0;  // wave-uniform: rays waiting in the pool, index of the first
     // optional per-wave timeline (diagnostic builds of the host set a.debug): start, queue-dry, end in 10 ns ticks
     uint64_t t_begin = 0, t_dry = 0;
@@ -1033,26 +994,38 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
         uint64_t act = __ballot((int32_t)st < 0);  // ST_ACTIVE is the sign bit: one compare
         const uint32_t n_idle = 64u - (uint32_t)__popcll(act);
         if (n_idle >= a.refill_min) {
-            if (pending && pool_n == 0u) {  // now the answer of the early claim is needed
-                pending = false;
-                const uint32_t sh = blockIdx.x % kShards;
-                const uint32_t k = __builtin_amdgcn_readfirstlane(pend) * kSubs + my_sub + ((gridDim.x + kShards - 1u - sh) / kShards) * (uint32_t)(BLOCK / 64);
-                uint32_t s = 0xFFFFFFFFu;
-                if (order) {
-                    if (k < order[sh]) s = order[kShards + sh * a.order_cap + k];
-                } else {
-                    const uint32_t cand = sh * per_shard + k;
-                    if (k < per_shard && cand < n_strips) s = cand;
+            if (next == 0xFFFFFFFEu && pool_n == 0u) {  // now the answer of the early claim is needed
+                uint32_t sh = home / kSubs;
+                uint32_t s = entry_of(sh, __builtin_amdgcn_readfirstlane(pend) * kSubs + home % kSubs + ((gridDim.x + kShards - 1u - sh) / kShards) * (uint32_t)(BLOCK / 64));
+                // The home counter ran out: lane i looks at counter i -- one load for all 64 -- and the wave draws from the first
+                // counter that still has entries, starting behind its own (the other counters of its list, then list by list), and
+                // makes that counter its home: later claims from it are issued ahead of time again (frames whose lists differ
+                // much in length -- secondary rays of the pixels that hit something -- would otherwise pay two round trips per
+                // strip).  Probing the counters one atomic after the other would cost a finished wave 64 round trips to find
+                // out that the frame is over.
+                while (s == 0xFFFFFFFFu) {
+                    const uint32_t l = lane / kSubs;
+                    const uint32_t cv = __hip_atomic_load(work_counter + lane * kShardStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t res_l = ((gridDim.x + kShards - 1u - l) / kShards) * (uint32_t)(BLOCK / 64);
+                    const uint32_t per_shard = (n_strips + kShards - 1) / kShards;
+                    const uint32_t len_l = order ? order[l] : min(per_shard, n_strips - min(n_strips, l * per_shard));
+                    const uint64_t has = __ballot((uint64_t)cv * kSubs + lane % kSubs + res_l < (uint64_t)len_l);
+                    if (!has) break;
+                    const uint64_t rot = home ? ((has >> home) | (has << (64u - home))) : has;
+                    home = (home + (uint32_t)__ffsll((unsigned long long)rot) - 1u) & 63u;
+                    sh = home / kSubs;
+                    uint32_t k = 0u;
+                    if (lane == 0) k = atomicAdd(work_counter + home * kShardStride, 1u);
+                    s = entry_of(sh, __builtin_amdgcn_readfirstlane(k) * kSubs + home % kSubs + ((gridDim.x + kShards - 1u - sh) / kShards) * (uint32_t)(BLOCK / 64));
                 }
-                if (s != 0xFFFFFFFFu) {
-                    next = __builtin_amdgcn_readfirstlane(s) * strip_items;
-                    strip_end = min(next + strip_items, n_items);
-                } else {  // the home list is exhausted: go on with the other lists, synchronously
-                    cur.shard_try = 1u;
-                    cur = claim(cur, false);
-                    next = cur.next;
-                    strip_end = cur.end;
-                }
+                // the next claim goes to the list's next counter: every wave of a list draws from all of its counters in turn, so
+                // the counters advance together and the list is consumed front to back, as with one counter (waves tied to one
+                // counter let the counters drift apart: a group of waves that got long strips leaves its share of the list's
+                // front -- long strips -- for the end; 4K frames with fused shadow rays lost 25 %)
+                home = (home & ~(kSubs - 1u)) | ((home + 1u) & (kSubs - 1u));
+                s = __builtin_amdgcn_readfirstlane(s);
+                next = s != 0xFFFFFFFFu ? s * strip_items : 0xFFFFFFFFu;
+                strip_end = s != 0xFFFFFFFFu ? min(next + strip_items, n_items) : 0xFFFFFFFFu;
                 if (DBG && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
             }
             const bool more = (pool_n != 0u) || (next != 0xFFFFFFFFu);
@@ -1067,7 +1040,7 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                     float gp0 = 0, gp1 = 0, gp2 = 0, gd0 = 1, gd1 = 1, gd2 = 1, gdist = 0;
                     uint32_t gout = 0;
                     if (q < strip_end) {
-                        ItemFast it = decode_item_wave(a.work, next, lane);
+                        ItemFast it = decode_item_fast(a.work, q);  // (decode_item_wave's scalar divisions cost this loop registers it does not have)
                         if (a.work.mode == 2 && a.skip && a.skip[q]) it.valid = false;  // no ray: the producer wrote the record
                         if (it.valid) {
                             RayIn r;
@@ -1120,15 +1093,8 @@ __global__ __launch_bounds__(BLOCK, CNT ? 5 : 6) void trace_stack_kernel(TraceAr
                     pool_i = 0u;
                     next += min(64u, strip_end - next);
                     if (next >= strip_end) {
-                        if (work_counter && cur.shard_try == 0u) {
-                            if (lane == 0) pend = atomicAdd(work_counter + ((blockIdx.x % kShards) * kSubs + my_sub) * kShardStride, 1u);
-                            pending = true;
-                            next = strip_end = 0xFFFFFFFEu;  // not known yet (and not "dry")
-                        } else {
-                            cur = claim(cur, false);
-                            next = cur.next;
-                            strip_end = cur.end;
-                        }
+                        if (lane == 0) pend = atomicAdd(work_counter + home * kShardStride, 1u);
+                        next = strip_end = 0xFFFFFFFEu;  // not known yet (and not "dry")
                     }
                     if (DBG && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
                     if (DBG) c_gen += (uint32_t)(__builtin_amdgcn_s_memtime() - c_g0);
