@@ -318,17 +318,15 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     return SVO_OK;
 }
 
-// Shadow rays inside the primary launch?  STACK variant, a sun direction the fast arithmetic covers (it is the same for every
-// shadow ray, so this is decided here; the origins are hit points inside the cube and always qualify), and -- in automatic
-// mode -- where it measured faster: deep trees (the shadow ray restarts from the primary ray's ancestor stack instead of
-// descending from the root: depth-20 fractal -24 % at 1080p) and large frames (depth-16 terrain: -8 % at 4K, but +5 % at
-// 1080p, where one lane's primary-plus-shadow chain lengthens the frame's tail more than the second launch costs).
+// Shadow rays inside the primary launch?  STACK variant and a sun direction the fast arithmetic covers (it is the same for every
+// shadow ray, so this is decided here; the origins are hit points inside the cube and always qualify).  Automatic mode fuses
+// whenever that holds: the shadow ray restarts from the primary ray's ancestor stack instead of descending from the root, and
+// there is one launch, one set of claims, one tail.  (Until the claim counters were split -- eight per list -- a 1080p frame
+// of the depth-16 terrain was 5 % slower fused and the automatic mode fused only deep trees, 4K frames and counting frames;
+// since then: 1080p 0.646 -> 0.581 ms, 4K 2.04 -> 1.78 ms, depth-20 fractal -24 %.)
 bool fuse_shadow_rays(const svo_ctx *ctx, size_t n_pixels) {
-    // (and with live hit counters: one launch shares the visit queue's start-up and the workgroup's table of saturated words
-    // between a primary ray and its shadow ray -- default mode 1.58 -> 1.47 ms at 1080p)
-    const bool counting = !(ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE);
-    const bool want = ctx->fused_shadows == 1 ||
-                      (ctx->fused_shadows == 2 && (ctx->tree_depth > (uint32_t)svo::stack_max_depth(false) || n_pixels >= (1u << 22) || counting));
+    (void)n_pixels;
+    const bool want = ctx->fused_shadows != 0;
     if (!want || ctx->variant != SVO_VARIANT_STACK || ctx->tree_depth > (uint32_t)svo::stack_max_depth(true)) return false;
     const float *sd = ctx->uniforms.sun_dir;
     const float sl = sqrtf((sd[0] * sd[0] + sd[1] * sd[1]) + sd[2] * sd[2]);
