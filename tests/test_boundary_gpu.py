@@ -242,3 +242,30 @@ def test_moving_camera_schedule_does_not_change_records(pkg, gpu):
             assert np.array_equal(x, y), f"frame {k} differs between SVO_OPT_SCHEDULE_MOTION 0x1204 and {floor:#x}"
     with pytest.raises(pkg.SvoError):
         gpu.set_option(pkg.gpu.OPT_SCHEDULE_MOTION, 13)
+
+
+def test_strip_claims_with_small_grids(pkg, gpu):
+    """The strips of a frame are claimed from 64 counters (8 per schedule list); a wave whose counter has run out probes all of
+    them and moves on.  With a grid of 1, 5 or 64 workgroups most lists have no wave of their own and nearly every strip is
+    reached by stealing: the frame must come out the same as with the full grid, with and without a schedule."""
+    cam, look = pkg.scenes.terrain_camera(0, 16)
+    words = pkg.scenes.terrain(seed=0, max_depth=16, cam=cam, lod_c=300.0, max_words=20_000_000)
+    W, H = 800, 450
+    gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+    render = pkg.Render(gpu, (W, H), words, capacity=words.size)
+    render.set_flags(pause_adaptive=True, shadows=False)
+    render.update(pkg.Settings(), pkg.Character(cam, look))
+    try:
+        ref = None
+        for grid in (0, 1, 5, 64):
+            gpu.set_option(pkg.gpu.OPT_GRID_BLOCKS, grid)
+            gpu.set_option(pkg.gpu.OPT_SCHEDULE, 2)  # (drops the lists: the first frame runs without a schedule, the second with one)
+            for k in range(2):
+                h = render.render()
+                gpu.sync()
+                h = h.cpu().numpy().copy()
+                if ref is None:
+                    ref = h
+                assert np.array_equal(h, ref), f"grid of {grid} workgroups, frame {k}: records differ"
+    finally:
+        gpu.set_option(pkg.gpu.OPT_GRID_BLOCKS, 0)
