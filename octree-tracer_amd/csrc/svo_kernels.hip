@@ -926,7 +926,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
         if (DBG) {  // per-wave timeline build only (SVO_OPT_DEBUG_BUFFER): the default instantiation carries none of this
             n_rounds += 1;
             const uint32_t nd = (uint32_t)__popcll(__ballot(st >= (ST_ACTIVE | ST_DESC)));
-            if (!CNT) dbg_desc_start += nd;
+            (void)nd;
             if (!CNT) dbg_desc_rounds += nd ? 1u : 0u;
         }
         // ---- 1. descent: one dependent word per level below the restart level (PAIRS: per two levels) ----
@@ -995,6 +995,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
         const uint32_t n_idle = 64u - (uint32_t)__popcll(act);
         if (n_idle >= a.refill_min) {
             if (next == 0xFFFFFFFEu && pool_n == 0u) {  // now the answer of the early claim is needed
+                const uint64_t c_w0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
                 uint32_t sh = home / kSubs;
                 uint32_t s = entry_of(sh, __builtin_amdgcn_readfirstlane(pend) * kSubs + home % kSubs + ((gridDim.x + kShards - 1u - sh) / kShards) * (uint32_t)(BLOCK / 64));
                 // The home counter ran out: lane i looks at counter i -- one load for all 64 -- and the wave draws from the first
@@ -1027,6 +1028,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                 next = s != 0xFFFFFFFFu ? s * strip_items : 0xFFFFFFFFu;
                 strip_end = s != 0xFFFFFFFFu ? min(next + strip_items, n_items) : 0xFFFFFFFFu;
                 if (DBG && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
+                if (DBG && !CNT) dbg_desc_start += (uint32_t)(__builtin_amdgcn_s_memtime() - c_w0);  // (slot 15: cycles spent waiting for claims)
             }
             const bool more = (pool_n != 0u) || (next != 0xFFFFFFFFu);
             if (more) {
@@ -1307,7 +1309,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
         d[12] = dbg_desc_iters;  // descent-loop iterations of the wave (one dependent load each)
         d[13] = dbg_desc_lanes;  // lanes inside the loop, summed over its iterations
         d[14] = dbg_desc_rounds; // rounds in which any lane descended
-        d[15] = dbg_desc_start;  // lanes that started a descent, summed over rounds
+        d[15] = dbg_desc_start;  // cycles spent waiting for the answers of strip claims (CNT: cycles spent counting)
         d[0] = (uint32_t)t_begin;
         d[1] = (uint32_t)(t_dry ? t_dry : t_end);
         d[2] = (uint32_t)t_end;

@@ -93,14 +93,13 @@ def main():
                              "descent": round(float(d[:, 9].sum() / max(rounds, 1)), 1), "step": round(float(d[:, 10].sum() / max(rounds, 1)), 1)},
         "counting": {"cycles_per_round": round(float(d[:, 15].sum() / max(rounds, 1)), 1), "level_loop_iters_per_round": round(float(d[:, 12].sum() / max(rounds, 1)), 2),
                      "flush_cycles_per_round": round(float(d[:, 13].sum() / max(rounds, 1)), 1), "flushes_per_wave": round(float(d[:, 14].mean()), 2)} if a.count else None,
+        "claim_wait_cycles_per_wave": int(d[:, 15].mean()) if not a.count else None,
         "cycles_per_generated_strip": round(float(d[:, 11].sum() / max(d[:, 7].sum(), 1)), 1),
         "shader_clock_ghz_in_kernel": round(float(np.median(life_cyc / np.maximum((d[:, 2] - d[:, 0]) * 10.0, 1))), 3),
         # descent shape: wave-level iterations (dependent loads) per round vs the mean over lanes
         "descent": {"wave_iters_per_round": round(float(d[:, 12].sum() / max(rounds, 1)), 2),
                     "wave_iters_per_descending_round": round(float(d[:, 12].sum() / max(d[:, 14].sum(), 1)), 2),
-                    "lane_levels_per_descending_lane": round(float(d[:, 13].sum() / max(d[:, 15].sum(), 1)), 2),
                     "lanes_in_loop_per_iter": round(float(d[:, 13].sum() / max(d[:, 12].sum(), 1)), 2),
-                    "descending_lanes_per_round": round(float(d[:, 15].sum() / max(rounds, 1)), 2),
                     "cycles_per_wave_iter": round(float(d[:, 9].sum() / max(d[:, 12].sum(), 1)), 1)},
         "last_ray_steps_by_end_decile": [int(np.median(d[np.argsort(end)][i * len(d) // 10:(i + 1) * len(d) // 10, 5])) for i in range(10)],
     }
