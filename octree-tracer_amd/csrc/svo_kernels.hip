@@ -723,8 +723,11 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
     uint32_t next, strip_end;
     auto entry_of = [=](uint32_t sh, uint32_t k) -> uint32_t {  // strip behind entry k of list sh (0xFFFFFFFF: past the end)
         if (order) return k < order[sh] ? order[kShards + sh * a.order_cap + k] : 0xFFFFFFFFu;
-        const uint32_t per_shard = (n_strips + kShards - 1) / kShards, cand = sh * per_shard + k;  // no schedule yet: 8 contiguous screen regions
-        return (k < per_shard && cand < n_strips) ? cand : 0xFFFFFFFFu;
+        // no schedule yet (the first frame of a layout): runs of 16 consecutive strips dealt round-robin to the 8 lists, so that the
+        // lists are equally long in work whatever part of the screen is expensive (8 contiguous regions left whole lists of sky
+        // idle early and their waves stealing, one probe and one synchronous claim per strip)
+        const uint32_t cand = (((k >> 4) * kShards + sh) << 4) | (k & 15u);
+        return cand < n_strips ? cand : 0xFFFFFFFFu;
     };
     {
         const uint32_t my_rank = (blockIdx.x / kShards) * (uint32_t)(BLOCK / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);  // among the waves that start on my list
@@ -1008,8 +1011,13 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                     const uint32_t l = lane / kSubs;
                     const uint32_t cv = __hip_atomic_load(work_counter + lane * kShardStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t res_l = ((gridDim.x + kShards - 1u - l) / kShards) * (uint32_t)(BLOCK / 64);
-                    const uint32_t per_shard = (n_strips + kShards - 1) / kShards;
-                    const uint32_t len_l = order ? order[l] : min(per_shard, n_strips - min(n_strips, l * per_shard));
+                    uint32_t len_l;
+                    if (order) {
+                        len_l = order[l];
+                    } else {  // (entry_of's deal: runs of 16 strips, run g belongs to list g mod 8; the last run may be short)
+                        const uint32_t runs = (n_strips + 15u) >> 4, mine = runs > l ? (runs - l + kShards - 1u) / kShards : 0u;
+                        len_l = (mine << 4) - ((runs != 0u && (runs - 1u) % kShards == l) ? (runs << 4) - n_strips : 0u);
+                    }
                     const uint64_t has = __ballot((uint64_t)cv * kSubs + lane % kSubs + res_l < (uint64_t)len_l);
                     if (!has) break;
                     const uint64_t rot = home ? ((has >> home) | (has << (64u - home))) : has;
