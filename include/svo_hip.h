@@ -88,7 +88,16 @@ typedef struct svo_ctx svo_ctx;
 
 /* kernel variants (svo_set_option SVO_OPT_VARIANT) */
 #define SVO_VARIANT_RESTART 0 /* reference-shaped: float-compare descent from the root every step */
-#define SVO_VARIANT_STACK 1   /* integer path codes + per-ray ancestor stack in LDS + LDS top table + refill */
+#define SVO_VARIANT_STACK 1   /* integer path codes + per-ray ancestor stack in LDS + LDS top table + refill (default).  Static trees
+                                 (pause_adaptive, or caller-supplied rays) of depth <= 16 without fused shadow rays are traced with TWO
+                                 rays per lane -- one ray's dependent load travels while the lane's other ray steps -- over a
+                                 device-built table with one word per node word (its child group and which of the 8 children are
+                                 empty leaves: a step into an empty leaf needs no load).  The table costs as much device memory as
+                                 the node buffer and is rebuilt by the first such trace after the words changed (one pass over the
+                                 array, one host synchronisation); arrays whose child groups are not 8-aligned inside the buffer
+                                 (Octree::subdivide always makes them so, octree.rs:72-90) and every other mode run one ray per lane.
+                                 Results do not depend on which kernel runs. */
+#define SVO_VARIANT_STACK1 2  /* the same, always one ray per lane (no table) */
 
 typedef enum svo_option {
     SVO_OPT_VARIANT = 0,
@@ -112,11 +121,8 @@ typedef enum svo_option {
                                    on with that pixel's shadow ray inside the primary launch; 0 = shadow rays are a second launch;
                                    2 (default) = automatic, which fuses whenever the sun direction is one the fast arithmetic covers
                                    (1080p: 0.65 -> 0.58 ms, 4K: 2.04 -> 1.78 ms on the benchmark tree).  The image is the same either way. */
-    SVO_OPT_PAIR_TABLE = 13, /* STACK variant, static trees (pause_adaptive): descend two levels per dependent load through a
-                                device-built table that stores, for every node word, the 8 words of its children (8 x the node
-                                buffer in HBM, built on the first trace after the words changed).  0 (default) off, 1 on: it
-                                halves the dependent loads but each one got slower, a net loss on the benchmark frame (DESIGN.md
-                                4.5).  Results do not depend on it. */
+    SVO_OPT_PAIR_TABLE = 13, /* accepted and ignored: the two-levels-per-load table of round 2 measured a net loss and left the library;
+                                the child-mask table of SVO_VARIANT_STACK took its place */
     SVO_OPT_CULL = 14,       /* pixel frames, STACK variant: 64-pixel blocks whose rays all miss the cube (decided conservatively from
                                 the block's corner rays) get their all-zero records from a pre-pass and are never claimed by the
                                 trace.  0 off, 1 whenever the camera is outside the cube, 2 (default) when in addition at least 40 % of a

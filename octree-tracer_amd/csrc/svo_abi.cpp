@@ -70,8 +70,10 @@ void release_store(svo_ctx *ctx) {
     if (!st || --st->refs > 0) return;
     (void)hipSetDevice(st->device);
     if (st->nodes && st->owned) (void)hipFree(st->nodes);
-    if (st->pairs) (void)hipFree(st->pairs);
-    if (st->pairs_ready) (void)hipEventDestroy(st->pairs_ready);
+    if (st->etab) (void)hipFree(st->etab);
+    if (st->etop) (void)hipFree(st->etop);
+    if (st->etab_flag) (void)hipFree(st->etab_flag);
+    if (st->etab_ready) (void)hipEventDestroy(st->etab_ready);
     if (st->last_write) (void)hipEventDestroy(st->last_write);
     delete st;
 }
@@ -92,36 +94,47 @@ int ensure_top_table(svo_ctx *ctx) {
     return SVO_OK;
 }
 
-// The pair table of the store (svo_ctx.h), built on first use after the words changed; *out stays nullptr when the table
-// is switched off, does not fit (address range or free memory) or the launch counts hits.
-int ensure_pairs(svo_ctx *ctx, const uint32_t **out) {
-    *out = nullptr;
+// The E table of the store (svo_dual.hip), built by the first static trace after the words changed; *ok stays false when the
+// table does not fit (address range or free memory) or the array has child groups it cannot name (unaligned or past the
+// buffer: the builder says so in a device word, read back once per build) -- the one-ray kernel then traces, same results.
+// (Traces other contexts still have in flight read the old table while it is rebuilt: like the node words themselves, a write
+// does not wait for them, see svo_nodes_share.)
+int ensure_etab(svo_ctx *ctx, bool *ok) {
+    *ok = false;
     svo_node_store *st = ctx->store;
-    if (!ctx->use_pairs || st->pairs_failed || st->capacity > svo::kPairsMaxWords) return SVO_OK;
-    if (st->pairs_version != st->version) {
-        const size_t bytes = (st->capacity + 1) * 8 * sizeof(uint32_t);
-        if (!st->pairs) {
+    if (st->etab_failed || st->capacity == 0 || st->capacity > (size_t(1) << 27)) return SVO_OK;
+    if (st->etab_version != st->version) {
+        if (!st->etab) {
+            const size_t bytes = st->capacity * sizeof(uint32_t);
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (size_t(1) << 30) ||
-                hipMalloc((void **)&st->pairs, bytes) != hipSuccess) {
+                hipMalloc((void **)&st->etab, bytes) != hipSuccess ||
+                hipMalloc((void **)&st->etop, 2 * svo::kTopEntries * sizeof(uint32_t)) != hipSuccess ||
+                hipMalloc((void **)&st->etab_flag, sizeof(uint32_t)) != hipSuccess) {
                 (void)hipGetLastError();
-                st->pairs = nullptr;
-                st->pairs_failed = true;  // stay on the one-level walk: same results, more dependent loads
+                if (st->etab) (void)hipFree(st->etab);
+                if (st->etop) (void)hipFree(st->etop);
+                st->etab = st->etop = nullptr;
+                st->etab_failed = true;
                 return SVO_OK;
             }
         }
         int rc = order_after_last_write(ctx);
         if (rc) return rc;
-        // (traces other contexts still have in flight read the old table: like the node words themselves, see svo_nodes_share)
-        HIP_TRY(ctx, svo::launch_build_pairs(st->nodes, (uint32_t)st->capacity, st->pairs, ctx->stream));
-        if (!st->pairs_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&st->pairs_ready, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventRecord(st->pairs_ready, ctx->stream));
-        st->pairs_builder = ctx->stream;
-        st->pairs_version = st->version;
-    } else if (st->pairs_builder != ctx->stream) {
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, st->pairs_ready, 0));
+        HIP_TRY(ctx, hipMemsetAsync(st->etab_flag, 0, sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, svo::launch_build_etab(st->nodes, (uint32_t)st->capacity, st->etab, st->etop, st->etab_flag, ctx->stream));
+        uint32_t bad = 1;
+        HIP_TRY(ctx, hipMemcpyAsync(&bad, st->etab_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        st->etab_ok = bad == 0;
+        if (!st->etab_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&st->etab_ready, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(st->etab_ready, ctx->stream));
+        st->etab_builder = ctx->stream;
+        st->etab_version = st->version;
+    } else if (st->etab_builder != ctx->stream) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, st->etab_ready, 0));
     }
-    *out = st->pairs;
+    *ok = st->etab_ok;
     return SVO_OK;
 }
 
@@ -174,7 +187,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     if (rc) return rc;
     // the kernel that runs: STACK resolves the levels its integer path codes cover (SVO_OPT_TREE_DEPTH says how deep the
     // caller's tree may be); deeper trees, and the debug view that reads counter bits, take the general RESTART kernel
-    const bool want_stack = ctx->variant == SVO_VARIANT_STACK && ctx->tree_depth <= (uint32_t)svo::stack_max_depth(true);
+    const bool want_stack = ctx->variant != SVO_VARIANT_RESTART && ctx->tree_depth <= (uint32_t)svo::stack_max_depth(true);
     if (want_stack) {
         rc = ensure_top_table(ctx);
         if (rc) return rc;
@@ -207,9 +220,15 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     const bool debug_hits = (ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE) && (ctx->uniforms.flags & SVO_F_SHOW_HITS);
     const bool stack = want_stack && !debug_hits;
     a.shadow_hits = stack ? opt.shadow_out : nullptr;
-    if (stack && !counting) {
-        rc = ensure_pairs(ctx, &a.pairs);
+    // two rays per lane over the E table (svo_dual.hip): static trees, no fused shadow rays, trees the default stack resolves
+    bool dual = false;
+    if (stack && !counting && !a.shadow_hits && ctx->variant == SVO_VARIANT_STACK && ctx->tree_depth <= (uint32_t)svo::dual_max_depth()) {
+        rc = ensure_etab(ctx, &dual);
         if (rc) return rc;
+        if (dual) {
+            a.etab = ctx->store->etab;
+            a.top_table = ctx->store->etop;
+        }
     }
     const uint32_t n_strips = (wd.n_items + 63u) / 64u;
     const bool schedule = ctx->schedule && n_strips <= svo::kMaxScheduledStrips;
@@ -256,6 +275,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     li.strip_items = ctx->strip_items;
     li.deep_stack = ctx->tree_depth > (uint32_t)svo::stack_max_depth(false);
     li.occupancy = ctx->occupancy;
+    li.dual = dual;
     if (stack && ctx->defer_items < wd.n_items) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->defer_buf) (void)hipFree(ctx->defer_buf);
@@ -327,7 +347,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
 bool fuse_shadow_rays(const svo_ctx *ctx, size_t n_pixels) {
     (void)n_pixels;
     const bool want = ctx->fused_shadows != 0;
-    if (!want || ctx->variant != SVO_VARIANT_STACK || ctx->tree_depth > (uint32_t)svo::stack_max_depth(true)) return false;
+    if (!want || ctx->variant == SVO_VARIANT_RESTART || ctx->tree_depth > (uint32_t)svo::stack_max_depth(true)) return false;
     const float *sd = ctx->uniforms.sun_dir;
     const float sl = sqrtf((sd[0] * sd[0] + sd[1] * sd[1]) + sd[2] * sd[2]);
     for (int k = 0; k < 3; k++) {
@@ -628,7 +648,7 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
     if (!ctx) return SVO_ERR_ARG;
     switch (option) {
         case SVO_OPT_VARIANT:
-            if (value != SVO_VARIANT_RESTART && value != SVO_VARIANT_STACK) return fail(ctx, SVO_ERR_ARG, "unknown variant");
+            if (value != SVO_VARIANT_RESTART && value != SVO_VARIANT_STACK && value != SVO_VARIANT_STACK1) return fail(ctx, SVO_ERR_ARG, "unknown variant");
             ctx->variant = (int)value;
             return SVO_OK;
         case SVO_OPT_TIMING: {
@@ -689,9 +709,7 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
             if (value < 0 || value > 2) return fail(ctx, SVO_ERR_ARG, "cull: 0 (off), 1 (whenever the camera is outside the cube) or 2 (automatic)");
             ctx->cull_mode = (int)value;
             return SVO_OK;
-        case SVO_OPT_PAIR_TABLE:
-            if (value < 0 || value > 1) return fail(ctx, SVO_ERR_ARG, "pair table: 0 (off) or 1 (on)");
-            ctx->use_pairs = (int)value;
+        case SVO_OPT_PAIR_TABLE:  // (the table left the library; the E table of svo_dual.hip took its place)
             return SVO_OK;
         case SVO_OPT_DEBUG_BUFFER:
             ctx->debug_buf = (uint32_t *)(uintptr_t)value;  // device pointer, 64 B per wave of the grid; 0 = off
@@ -720,6 +738,10 @@ int svo_sync(svo_ctx *ctx) {
     // surface device-side errors raised by trace kernels
     uint32_t st = 0;
     HIP_TRY(ctx, hipMemcpy(&st, ctx->status, sizeof(st), hipMemcpyDeviceToHost));
+    if (st & 4u) {  // (bring-up builds of the two-ray kernel only: SVO_DUAL_GUARD)
+        HIP_TRY(ctx, hipMemset(ctx->status, 0, sizeof(uint32_t)));
+        return fail(ctx, SVO_ERR_STATE, "a wave of the two-ray kernel ran into its iteration guard");
+    }
     if (st & 2u) {
         HIP_TRY(ctx, hipMemset(ctx->status, 0, sizeof(uint32_t)));
         return fail(ctx, SVO_ERR_STATE, "fused shadow ray outside the range of the fast arithmetic (set SVO_OPT_FUSED_SHADOWS to 0)");

@@ -23,12 +23,14 @@ struct svo_node_store {
     uint64_t version = 1;        // bumped whenever the words may have changed
     hipEvent_t last_write = nullptr;   // recorded on the writing context's stream after every write
     hipStream_t last_writer = nullptr; // that stream: other streams wait for the event before they read
-    // pair table of the STACK kernel: for every word p its 8 children, 8 * (capacity + 1) words
-    uint32_t *pairs = nullptr;
-    uint64_t pairs_version = 0;  // store version the table was built from (0: never)
-    bool pairs_failed = false;   // allocation failed once: stay on the one-level descent
-    hipEvent_t pairs_ready = nullptr;   // recorded behind the build on the building context's stream
-    hipStream_t pairs_builder = nullptr;
+    // E table of the dual kernel (svo_dual.hip): one word per node word + the top table made from it (2 * kTopEntries words)
+    uint32_t *etab = nullptr, *etop = nullptr;
+    uint32_t *etab_flag = nullptr;   // device word: the builder found a child group the table cannot name
+    uint64_t etab_version = 0;   // store version the table was built from (0: never)
+    bool etab_ok = false;        // that version is traceable through the table
+    bool etab_failed = false;    // allocation failed once: stay on the one-ray kernel
+    hipEvent_t etab_ready = nullptr;   // recorded behind the build on the building context's stream
+    hipStream_t etab_builder = nullptr;
 };
 
 struct svo_ctx {
@@ -42,7 +44,6 @@ struct svo_ctx {
     size_t capacity = 0;
     uint64_t top_version = 0;    // store version this context's top table was built from (0: none)
     uint32_t *top_table = nullptr;
-    int use_pairs = 0;           // SVO_OPT_PAIR_TABLE
     int cull_mode = 2;           // SVO_OPT_CULL
     bool cam_shortcut = true;    // SVO_OPT_CAMERA_SHORTCUT
     void *comm = nullptr;        // ncclComm_t (svo_comm.cpp); world size and rank of this context in it

@@ -19,174 +19,10 @@
 #include <hip/hip_runtime.h>
 
 #include "svo_device.h"
+#include "svo_trace_fn.h"
 
 namespace svo {
 
-// ---------------------------------------------------------------------------------------------
-// strict-f32 helpers (definitions shared with oracle/svo_oracle.c)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float fmin_w(float a, float b) { return (b < a) ? b : a; }
-__device__ __forceinline__ float fmax_w(float a, float b) { return (a < b) ? b : a; }
-__device__ __forceinline__ float sign_w(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
-
-__device__ __forceinline__ uint32_t normal_code(float n) {
-    return (n == 0.0f) ? 0u : ((n == 1.0f) ? 1u : ((n == -1.0f) ? 2u : 3u));
-}
-
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-
-__device__ __forceinline__ rsrc_t make_rsrc(const uint32_t *p, uint32_t n_words) {
-    // raw buffer, stride 0, num_records in bytes; 0x00020000 = DATA_FORMAT 32 (gfx9 raw dword)
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p), 0, (int)(n_words << 2), 0x00020000);
-}
-
-__device__ __forceinline__ uint32_t load_word(rsrc_t rs, uint32_t idx) {
-    // idx < 2^30 on every path that reaches here (descents use pointers < 2^27 + 8)
-    return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(idx << 2), 0, 0);
-}
-
-struct RayIn {
-    float px, py, pz, dx, dy, dz;
-};
-
-// mat4 * vec4, column-major, ((c0*x + c1*y) + c2*z) + c3*w
-__device__ __forceinline__ void mat_vec(const float *m, float x, float y, float z, float w, float out[4]) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) out[r] = ((m[r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w;
-}
-
-// Ray generation, shader.wgsl:54-59,253-259
-__device__ __forceinline__ RayIn gen_ray(const svo_uniforms &u, uint32_t px, uint32_t py) {
-    float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-    float cx = fx / u.dimensions[0] * 2.0f;
-    float cy = fy / u.dimensions[1] * 2.0f;
-    cx = cx - 1.0f;
-    cy = cy - 1.0f;
-    cy = cy * -1.0f;
-    float p4[4], d4[4];
-    mat_vec(u.camera_inverse, 0.0f, 0.0f, 0.0f, 1.0f, p4);
-    mat_vec(u.camera_inverse, cx, cy, 1.0f, 1.0f, d4);
-    RayIn r;
-    r.px = p4[0] / p4[3];
-    r.py = p4[1] / p4[3];
-    r.pz = p4[2] / p4[3];
-    float dx = d4[0] / d4[3] - r.px, dy = d4[1] / d4[3] - r.py, dz = d4[2] / d4[3] - r.pz;
-    float len = sqrtf((dx * dx + dy * dy) + dz * dz);
-    r.dx = dx / len;
-    r.dy = dy / len;
-    r.dz = dz / len;
-    return r;
-}
-
-// in_bounds, shader.wgsl:177-180
-__device__ __forceinline__ bool in_bounds(float x, float y, float z) {
-    float s0 = ((-1.0f <= x) ? 1.0f : 0.0f) - ((1.0f <= x) ? 1.0f : 0.0f);
-    float s1 = ((-1.0f <= y) ? 1.0f : 0.0f) - ((1.0f <= y) ? 1.0f : 0.0f);
-    float s2 = ((-1.0f <= z) ? 1.0f : 0.0f) - ((1.0f <= z) ? 1.0f : 0.0f);
-    return (s0 * s1 * s2) > 0.5f;
-}
-
-// ray_box_dist against [-1,1]^3, shader.wgsl:66-80 (uses the UNBIASED direction)
-__device__ __forceinline__ float ray_box_dist(const RayIn &r) {
-    float v1 = (-1.0f - r.px) / r.dx, v2 = (1.0f - r.px) / r.dx;
-    float v3 = (-1.0f - r.py) / r.dy, v4 = (1.0f - r.py) / r.dy;
-    float v5 = (-1.0f - r.pz) / r.dz, v6 = (1.0f - r.pz) / r.dz;
-    float v7 = fmax_w(fmax_w(fmin_w(v1, v2), fmin_w(v3, v4)), fmin_w(v5, v6));
-    float v8 = fmin_w(fmin_w(fmax_w(v1, v2), fmax_w(v3, v4)), fmax_w(v5, v6));
-    if (v8 < 0.0f || v7 > v8) return 0.0f;
-    return v7;
-}
-
-// octree_ray prologue, shader.wgsl:192-212.  false: the ray never enters the cube (value 0).
-__device__ __forceinline__ bool ray_enter(const RayIn &r, float pos[3], float dir[3], float &dist) {
-    dir[0] = r.dx + ((r.dx == 0.0f) ? 1.0f : 0.0f) * 0.000001f;
-    dir[1] = r.dy + ((r.dy == 0.0f) ? 1.0f : 0.0f) * 0.000001f;
-    dir[2] = r.dz + ((r.dz == 0.0f) ? 1.0f : 0.0f) * 0.000001f;
-    pos[0] = r.px; pos[1] = r.py; pos[2] = r.pz;
-    dist = 0.0f;
-    if (!in_bounds(r.px, r.py, r.pz)) {
-        dist = ray_box_dist(r);
-        if (dist == 0.0f) return false;
-        pos[0] = r.px + dir[0] * dist;
-        pos[1] = r.py + dir[1] * dist;
-        pos[2] = r.pz + dir[2] * dist;
-    }
-    return true;
-}
-
-__device__ __forceinline__ void write_hit(svo_hit *hits, uint32_t out, uint32_t value, float t, uint32_t steps,
-                                          uint32_t depth, uint32_t hit, uint32_t ncode) {
-    uint4 rec;
-    rec.x = value;
-    rec.y = __float_as_uint(t);
-    rec.z = (steps & 0xFFu) | ((depth & 0xFFu) << 8) | (hit << 16) | (ncode << 17);
-    rec.w = ncode;
-    reinterpret_cast<uint4 *>(hits)[out] = rec;
-}
-
-__device__ __forceinline__ float code_to_normal(uint32_t c) { return c == 1u ? 1.0f : (c == 2u ? -1.0f : 0.0f); }
-
-// normalize(u.sun_dir.xyz), shader.wgsl:275
-__device__ __forceinline__ void sun_direction(const svo_uniforms &u, float s[3]) {
-    const float sl = sqrtf((u.sun_dir[0] * u.sun_dir[0] + u.sun_dir[1] * u.sun_dir[1]) + u.sun_dir[2] * u.sun_dir[2]);
-    s[0] = u.sun_dir[0] / sl; s[1] = u.sun_dir[1] / sl; s[2] = u.sun_dir[2] / sl;
-}
-
-// Where the secondary rays of a hit start (shader.wgsl:276): HitInfo.pos + normal * 2.5e-6, with HitInfo.pos the
-// voxel_pos of the last step (the entry point when no step was taken) rebuilt from the primary ray (pos, dir: after
-// ray_enter), the record's step count and normal codes, and t_current of the last step.
-__device__ __forceinline__ void secondary_origin(const float pos[3], const float dir[3], uint32_t steps, uint32_t ncode, float t,
-                                                 float org[3], float n[3]) {
-    n[0] = code_to_normal(ncode & 3u); n[1] = code_to_normal((ncode >> 2) & 3u); n[2] = code_to_normal((ncode >> 4) & 3u);
-    float h0 = pos[0], h1 = pos[1], h2 = pos[2];
-    if (steps != 0u) {
-        h0 = pos[0] + dir[0] * t - n[0] * 0.000002f;
-        h1 = pos[1] + dir[1] * t - n[1] * 0.000002f;
-        h2 = pos[2] + dir[2] * t - n[2] * 0.000002f;
-    }
-    org[0] = h0 + n[0] * 0.0000025f; org[1] = h1 + n[1] * 0.0000025f; org[2] = h2 + n[2] * 0.0000025f;
-}
-
-struct Item {
-    bool valid;
-    uint32_t out, px, py;
-};
-
-__device__ __forceinline__ Item decode_item(const WorkDesc &w, uint32_t q) {
-    Item it;
-    if (w.mode == 2) {
-        it.valid = q < w.n_items;
-        it.out = q;
-        it.px = it.py = 0;
-        return it;
-    }
-    uint32_t blk = q >> 6, lane = q & 63u;
-    uint32_t rect = blk / w.bprect;
-    uint32_t b = blk - rect * w.bprect;
-    uint32_t by = b / w.bpr, bx = b - by * w.bpr;
-    uint32_t x = (bx << w.bw_log2) + (lane & ((1u << w.bw_log2) - 1u)), y = (by << (6u - w.bw_log2)) + (lane >> w.bw_log2);
-    it.valid = (q < w.n_items) && (x < w.w) && (y < w.h);
-    it.out = rect * (w.w * w.h) + y * w.w + x;
-    uint32_t ox = w.x0, oy = w.y0;
-    if (w.mode == 1) {
-        uint32_t t = w.first_tile + rect * w.tile_stride;
-        uint32_t ty = t / w.tiles_x;
-        ox = (t - ty * w.tiles_x) * w.w;
-        oy = ty * w.h;
-    }
-    it.px = ox + x;
-    it.py = oy + y;
-    return it;
-}
-
-__device__ __forceinline__ RayIn item_ray(const TraceArgs &a, const Item &it) {
-    if (a.work.mode == 2) {
-        const float *p = a.rays + 6ull * it.out;
-        RayIn r = {p[0], p[1], p[2], p[3], p[4], p[5]};
-        return r;
-    }
-    return gen_ray(a.u, it.px, it.py);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Variant RESTART: the reference's algorithm shape -- float-compare descent from the root on
@@ -393,220 +229,21 @@ __global__ __launch_bounds__(256) void build_top_table_kernel(const uint32_t *no
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pair table: two octree levels per dependent load.  Row p (8 words) holds, for node word p, what a ray
-// finds one level further down: the 8 words of p's child group -- or, when p is a leaf, 8 copies of p itself with bit 0
-// set ("the walk ended one level early").  A descent step that knows the child group G of level a and the child choices
-// c1 (level a) and c2 (level a + 1) reads pairs[(G + c1) * 8 + c2] and is two levels further down, where the node array
-// needs word G + c1 first and then a second, dependent load.  Counter bits (the low four) are not copied: the table is
-// used while the tree is static (pause_adaptive) and rebuilt when the words change.  Row n_words stands for "a word past
-// the end of the buffer" (reads as 0: interior, child group 0), which keeps the walk identical to load_word's
-// out-of-range rule for malformed arrays.
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t kPairEarly = 1u;
-
-__global__ __launch_bounds__(256) void build_pairs_kernel(const uint32_t *nodes, uint32_t n_words, uint32_t *pairs) {
-    const rsrc_t rs = make_rsrc(nodes, n_words);
-    for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p <= n_words; p += gridDim.x * 256u) {
-        const uint32_t w = load_word(rs, p);  // p == n_words: out of range, 0
-        uint32_t v[8];
-        if ((w >> 4) >= kVoxelOffset) {
-#pragma unroll
-            for (int c = 0; c < 8; c++) v[c] = (w & ~15u) | kPairEarly;
-        } else {
-            const uint32_t q = w >> 4;
-#pragma unroll
-            for (int c = 0; c < 8; c++) v[c] = load_word(rs, q + (uint32_t)c) & ~15u;
-        }
-        uint4 *dst = reinterpret_cast<uint4 *>(pairs + 8ull * p);
-        dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
-        dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
-    }
-}
-
-hipError_t launch_build_pairs(const uint32_t *nodes, uint32_t n_words, uint32_t *pairs, hipStream_t stream) {
-    (void)hipGetLastError();
-    uint32_t blocks = (n_words + 256u) / 256u;
-    if (blocks > 65536u) blocks = 65536u;
-    hipLaunchKernelGGL(build_pairs_kernel, dim3(blocks), dim3(256), 0, stream, nodes, n_words, pairs);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
 // Variant STACK (see file header).
 // ---------------------------------------------------------------------------------------------
-// Path code of a position: bit (D - d) of the code is the child choice `pos > centre` (or `>=`)
-// at level d.  General form (any float, NaN included): used at ray entry.
-__device__ __forceinline__ int32_t path_code(float v, bool ge_mode) {
-    // exact: v * 2^23 only moves the exponent; fmaxf/fminf (IEEE maxNum/minNum) send NaN to the bound,
-    // which reproduces "every comparison false" (code 0)
-    float g = fminf(fmaxf(v * 8388608.0f, -8388608.0f), 8388608.0f);
-    int32_t i = ge_mode ? (int32_t)floorf(g) : ((int32_t)ceilf(g) - 1);
-    i += 8388608;
-    i = i < 0 ? 0 : i;
-    i = i > 0x00FFFFFF ? 0x00FFFFFF : i;
-    return i;
-}
-
-// n / d for n*d_err < 2^32 with one fix-up step; magic = floor(2^32 / d) + 1 (d >= 2), d == 1 handled by magic 0
-__device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t d, uint32_t magic) {
-    if (magic == 0u) return n;
-    uint32_t q = __umulhi(n, magic);
-    uint32_t r = n - q * d;
-    return (r >= d) ? q - 1u : q;  // r wrapped below zero when q overshot by one
-}
-
-struct ItemFast {
-    bool valid;
-    uint32_t out, px, py;
-};
-
-__device__ __forceinline__ ItemFast decode_item_fast(const WorkDesc &w, uint32_t q) {
-    ItemFast it;
-    if (w.mode == 2) {
-        it.valid = q < w.n_items;
-        it.out = q;
-        it.px = it.py = 0;
-        return it;
-    }
-    uint32_t blk = q >> 6, lane = q & 63u;
-    uint32_t rect = 0, b = blk;
-    if (w.n_rects > 1u) {
-        rect = fast_div(blk, w.bprect, w.magic_bprect);
-        b = blk - rect * w.bprect;
-    }
-    uint32_t by = fast_div(b, w.bpr, w.magic_bpr), bx = b - by * w.bpr;
-    uint32_t x = (bx << w.bw_log2) + (lane & ((1u << w.bw_log2) - 1u)), y = (by << (6u - w.bw_log2)) + (lane >> w.bw_log2);
-    it.valid = (q < w.n_items) && (x < w.w) && (y < w.h);
-    it.out = rect * (w.w * w.h) + y * w.w + x;
-    uint32_t ox = w.x0, oy = w.y0;
-    if (w.mode == 1) {
-        uint32_t t = w.first_tile + rect * w.tile_stride;
-        uint32_t ty = fast_div(t, w.tiles_x, w.magic_tiles_x);
-        ox = (t - ty * w.tiles_x) * w.w;
-        oy = ty * w.h;
-    }
-    it.px = ox + x;
-    it.py = oy + y;
-    return it;
-}
-
-// The same for the 64 items of one block, lane by lane: `first` is the item of lane 0 -- a multiple of 64 and the same on every
-// lane, so the block's row, column and rectangle are found once per wave on the scalar unit (three divisions by
-// multiplication: ~80 vector instructions per generated strip when done per lane) and only the position inside the block
-// is per-lane work.
-__device__ __forceinline__ ItemFast decode_item_wave(const WorkDesc &w, uint32_t first, uint32_t lane) {
-    ItemFast it;
-    const uint32_t q = first + lane;
-    if (w.mode == 2) {
-        it.valid = q < w.n_items;
-        it.out = q;
-        it.px = it.py = 0;
-        return it;
-    }
-    const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 6));
-    uint32_t rect = 0, b = blk;
-    if (w.n_rects > 1u) {
-        rect = fast_div(blk, w.bprect, w.magic_bprect);
-        b = blk - rect * w.bprect;
-    }
-    const uint32_t by = fast_div(b, w.bpr, w.magic_bpr), bx = b - by * w.bpr;
-    uint32_t ox = w.x0, oy = w.y0;
-    if (w.mode == 1) {
-        const uint32_t t = w.first_tile + rect * w.tile_stride;
-        const uint32_t ty = fast_div(t, w.tiles_x, w.magic_tiles_x);
-        ox = (t - ty * w.tiles_x) * w.w;
-        oy = ty * w.h;
-    }
-    const uint32_t x0 = bx << w.bw_log2, y0 = by << (6u - w.bw_log2), out0 = rect * (w.w * w.h) + y0 * w.w + x0;  // (scalar)
-    const uint32_t lx = lane & ((1u << w.bw_log2) - 1u), ly = lane >> w.bw_log2;
-    const uint32_t x = x0 + lx, y = y0 + ly;
-    it.valid = (q < w.n_items) && (x < w.w) && (y < w.h);
-    it.out = out0 + ly * w.w + lx;
-    it.px = ox + x;
-    it.py = oy + y;
-    return it;
-}
-
-// a / d given y = RN(1 / d):  q0 = a*y,  r = a - d*q0 (exact, one fma),  q0 + r*y rounded once -- the same bits as
-// IEEE a / d.  Markstein's theorem gives this for a faithful q0; that q0 = RN(a*y) is always good enough is
-// established exhaustively: tools/divtest_gpu.hip compares the sequence with a / d for all 2^23 x 2^23 pairs
-// of significands (0 mismatches, profiles/r01_divtest_gpu.log; the uncorrected product fails on 27 %).  The
-// sequence is invariant under power-of-two scaling and sign changes while nothing over/underflows: the caller
-// guarantees 2^-17 <= |d| <= 2^63 and a == 0 or 2^-26 <= |a| <= 2^26 (grid units), so q0 and r stay normal.
-__device__ __forceinline__ float div_by_recip(float a, float d, float y) {
-    const float q = a * y;
-    const float r = __builtin_fmaf(-d, q, a);
-    return __builtin_fmaf(r, y, q);
-}
-
-// floor(x) and floor(-x) = -ceil(x) as integers in one instruction (|x| < 2^24 here, no saturation involved)
-__device__ __forceinline__ int32_t cvt_floor_i32(float x) {
-    int32_t r;
-    asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ int32_t cvt_floor_neg_i32(float x) {
-    int32_t r;
-    asm("v_cvt_flr_i32_f32_e64 %0, -%1" : "=v"(r) : "v"(x));
-    return r;
-}
-
-// path code of a finite position given in grid units (|g| <= 2^24), clamped into the cube like path_code()
-template <bool GE>
-__device__ __forceinline__ int32_t entry_code(float g) {
-    const int32_t i = GE ? cvt_floor_i32(g) + 8388608 : 8388607 - cvt_floor_neg_i32(g);
-    return min(max(i, 0), 0x00FFFFFF);
-}
-
-__device__ __forceinline__ float copysign_bits(float mag, float sgn) {
-    return __uint_as_float((__float_as_uint(mag) & 0x7FFFFFFFu) | (__float_as_uint(sgn) & 0x80000000u));
-}
-
-// "clean" ray: every quantity of the stepping arithmetic stays finite and inside the ranges the fast
-// forms above are proven for.  pos is the entry point (|pos| <= 2 always holds for rays that enter).
-__device__ __forceinline__ bool clean_component(float p, float d) {
-    float ap = fabsf(p), ad = fabsf(d);
-    bool p_ok = ap <= 2.0f;  // any magnitude below: scaling by 2^23 is exact, and A = (C - P) + H is 0 or >= 2^-26
-    bool d_ok = (ad >= 9.094947017729282e-13f) && (ad <= 1099511627776.0f);     // 2^-40 .. 2^40
-    return p_ok && d_ok;  // NaN fails both
-}
-
-// Per-lane state word: bits 0..7 steps | 8..12 leaf depth L | 13..15 step mask (axes of the last step's
-// normal) | 16 normal-is-entry-normal | 31 active | 30 needs descent (only ever set together with active) | 21 record pending | 22..24 how it ended
-constexpr uint32_t ST_L_SHIFT = 8, ST_M_SHIFT = 13;
-constexpr uint32_t ST_ENTRY = 1u << 16, ST_ACTIVE = 1u << 31, ST_DESC = 1u << 30;
-constexpr uint32_t ST_SHADOW = 1u << 17;  // SHD instantiation: the lane traces the shadow ray of the pixel in `out`
-// a finished ray keeps its state until the lane is refilled: record not yet written + how it ended
-constexpr uint32_t ST_PENDING = 1u << 21, ST_F_TOODEEP = 1u << 22, ST_F_SOLID = 1u << 23, ST_F_INB = 1u << 24;
-constexpr uint32_t ST_L_MASK = 31u << ST_L_SHIFT, ST_M_MASK = 7u << ST_M_SHIFT;
-
-// Ray pool: a wave generates the rays of up to 64 work items at once, with every lane busy (lanes that
-// are still traversing compute a ray for somebody else), compacts the ones that enter the cube into LDS,
-// and idle lanes later pick them up.  Ray generation and set-up (2 mat-vecs, 14 IEEE divisions, a square
-// root) are thereby paid once per 64 rays at full lane utilisation instead of on
-// every refill.  Pool record: P.xyz, Dr.xyz, Y.xyz (position, biased direction and its reciprocal, all in
-// grid units, see below), dist, out | entry normal code << 26.  (The entry path codes are recomputed at pick-up:
-// 11 words per ray keep a workgroup at 26 KiB of LDS, i.e. 6 workgroups per CU.)
-constexpr int kPoolWords = 11;
-constexpr int kCountQueue = 128;  // CNT: queued (word, visits) pairs per wave
-constexpr int kSatTags = 512;     // CNT: words known to be saturated, direct-mapped, per workgroup
 
 // The traversal runs in GRID UNITS: positions and directions are pre-multiplied by 2^23 (the path-code
 // scale).  Scaling by a power of two commutes with every IEEE rounding involved (no overflow/underflow on
 // a clean ray), so  A = (C - P) + H,  t = A / Dr,  G = (P + Dr * t) +- K  are exactly 2^23 times the
 // reference's  a,  the same t,  and  2^23 * voxel_pos  -- and G is what the path codes need.
 // CNT: hit counters live (adaptive mode, shader.wgsl:157-161), see step 3a in the loop.
-// PAIRS: descend through the pair table, two levels per load (static trees; never together with CNT, which needs the
-// address of every word on the path).
-template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD, bool PAIRS>
+template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD>
 __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
     constexpr int SMAX = K + 1 + NS;   // last level kept on the LDS stack = deepest level resolved
     static_assert(SMAX <= D - 1, "stack deeper than the path codes");
-    static_assert(!(PAIRS && CNT), "the counting instantiation walks every word");
-    constexpr uint32_t kTag = 0x80000000u;  // PAIRS: stack entry = child group of the level ABOVE the row's level
     constexpr int TBL = 1 << (3 * K);
     constexpr float kScale = 8388608.0f;  // 2^23
     constexpr float kInvScale = 1.0f / 8388608.0f;
@@ -680,8 +317,6 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
         if (n) cq[cq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = p | (min(n, 15u) << 27);
         cq_n += (uint32_t)__popcll(m);
     };
-    // the pair table: (n_words + 1) rows of 32 bytes (the host keeps n_words + 1 below 2^27, so byte offsets fit 32 bits)
-    const rsrc_t rp = PAIRS ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.pairs), 0, (int)((a.n_words + 1u) << 5), 0x00020000) : rs;
 
     for (uint32_t i = tid; i < (uint32_t)TBL; i += BLOCK) tbl[i] = a.top_table[i];
     __syncthreads();
@@ -770,8 +405,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
             addr = top ? cell : addr;
         }
         const uint32_t e = lds[addr];
-        // PAIRS: a tagged stack entry is the child group of level r - 1 (the walk went through level r without stopping)
-        lvl = top ? (e >> 27) : (PAIRS ? r - (e >> 31) : r);
+        lvl = top ? (e >> 27) : r;
         nidx = e & 0x07FFFFFFu;
     };
 
@@ -784,13 +418,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
         uint32_t ncode = ((nm & 1u) ? c0n : 0u) | ((nm & 2u) ? (c1n << 2) : 0u) | ((nm & 4u) ? (c2n << 4) : 0u);
         if (st & ST_ENTRY) ncode = out >> 26;             // no step taken: the entry normal
         if (!stop_here && !inb) ncode = 0u;               // left the cube: the miss record carries no normal
-        uint32_t leaf_index = leaf_off >> 2;
-        if (PAIRS && solid && (leaf_off & 1u)) {
-            // the leaf was found one level below word leaf_off >> 2, whose pointer the walk never read: read it now
-            const uint32_t bit = (uint32_t)D - L;
-            leaf_index = (load_word(rs, leaf_off >> 2) >> 4) +
-                         ((((uint32_t)ix >> bit) & 1u) << 2 | (((uint32_t)iy >> bit) & 1u) << 1 | (((uint32_t)iz >> bit) & 1u));
-        }
+        const uint32_t leaf_index = leaf_off >> 2;
         const uint32_t value = too_deep ? 0xFF000000u : (solid ? leaf_index : (!inb ? 0x20202000u : 0xFF000000u));
         const uint32_t depth = (too_deep || (!solid && inb)) ? 100u : L;
         const uint32_t hit = (stop_here || inb) ? 1u : 0u;
@@ -901,7 +529,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
     // first step in the same round.
     // (Not with live hit counters: the copied leaf word would carry the counter bits it had when the wave started, and
     // every ray's compare-and-swap on that one word would fail once -- two million serialised atomics on one address.)
-    constexpr bool CAM = !PAIRS && !CNT;
+    constexpr bool CAM = !CNT;
     uint32_t camv = 0;
     bool cam_ok = false;  // wave-uniform
     if (CAM && a.cam_shortcut && a.work.mode != 2) {
@@ -932,56 +560,8 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
             (void)nd;
             if (!CNT) dbg_desc_rounds += nd ? 1u : 0u;
         }
-        // ---- 1. descent: one dependent word per level below the restart level (PAIRS: per two levels) ----
-        if (PAIRS && st >= (ST_ACTIVE | ST_DESC)) {
-            uint32_t sh = (uint32_t)D - lvl + 1u;  // (bit of the path codes that selects the child of level lvl) + 1
-            // stack row of level lvl + 1 (rows: levels SBASE .. SMAX + 1; a walk that starts above level K + 1 dumps into row 0)
-            uint32_t row = max(lvl, (uint32_t)(SBASE - 1)) - (uint32_t)(SBASE - 1);
-            uint32_t w, p1;
-            int32_t key;
-            do {
-                if (DBG) {
-                    const uint64_t in_loop = __ballot(true);
-                    if (lane == (uint32_t)__ffsll((unsigned long long)in_loop) - 1u) {
-                        if (!CNT) dbg_desc_iters += 1u;
-                        if (!CNT) dbg_desc_lanes += (uint32_t)__popcll(in_loop);
-                    }
-                }
-                // levels a = D - (sh - 1) and a + 1: child choices c1, c2 from the path codes
-                uint32_t c1, c2, t1, t2;
-                asm("v_add_u32 %4, -1, %4\n\t"
-                    "v_bfe_u32 %0, %5, %4, 1\n\t"
-                    "v_bfe_u32 %2, %6, %4, 1\n\t"
-                    "v_lshl_or_b32 %0, %0, 1, %2\n\t"
-                    "v_bfe_u32 %2, %7, %4, 1\n\t"
-                    "v_lshl_or_b32 %0, %0, 1, %2\n\t"
-                    "v_add_u32 %4, -1, %4\n\t"
-                    "v_bfe_u32 %1, %5, %4, 1\n\t"
-                    "v_bfe_u32 %3, %6, %4, 1\n\t"
-                    "v_lshl_or_b32 %1, %1, 1, %3\n\t"
-                    "v_bfe_u32 %3, %7, %4, 1\n\t"
-                    "v_lshl_or_b32 %1, %1, 1, %3"
-                    : "=&v"(c1), "=&v"(c2), "=&v"(t1), "=&v"(t2), "+v"(sh)
-                    : "v"(ix), "v"(iy), "v"(iz));
-                p1 = min(nidx + c1, a.n_words);  // a pointer past the buffer reads the zero row, like load_word
-                w = __builtin_amdgcn_raw_buffer_load_b32(rp, (int)((p1 << 5) + (c2 << 2)), 0, 0);
-                lds[(uint32_t)TBL + min(row, (uint32_t)NS) * BLOCK + tid] = nidx | kTag;       // level a + 1: "come from level a"
-                lds[(uint32_t)TBL + min(row + 1u, (uint32_t)NS) * BLOCK + tid] = w >> 4;      // level a + 2
-                row += 2u;
-                nidx = w >> 4;
-                // done: the walk ended early (bit 0), or the word of level a + 1 is a leaf (bit 31), or level a + 1 >= SMAX
-                key = (int32_t)(w | (w << 31) | (sh - (uint32_t)(D - SMAX + 1)));
-            } while (key >= 0);
-            const bool early = (w & kPairEarly) != 0u;
-            uint32_t lb = (uint32_t)D - sh;                    // level a + 1
-            uint32_t lw = w & ~kPairEarly;
-            if (!early && lb > (uint32_t)SMAX) lw = 0u;       // level SMAX itself is interior: deeper than this kernel resolves
-            lvl = early ? lb - 1u : min(lb, (uint32_t)SMAX);
-            leaf_off = (p1 << 2) | (early ? 0u : 1u);         // bit 0: the leaf is a child of that word (flush_record)
-            leaf_w = lw;
-            st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
-        }
-        if (!PAIRS && st >= (ST_ACTIVE | ST_DESC)) descend();  // DESC implies ACTIVE: one unsigned compare
+        // ---- 1. descent: one dependent word per level below the restart level ----
+        if (st >= (ST_ACTIVE | ST_DESC)) descend();  // DESC implies ACTIVE: one unsigned compare
         if (DBG) {
             const uint64_t now = __builtin_amdgcn_s_memtime();
             c_desc += (uint32_t)(now - c_mark);
@@ -1763,21 +1343,17 @@ template <bool GE, int NS>
 static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
     const uint32_t strip_items = args.order ? 64u : (li.strip_items ? li.strip_items : 64u);
     const bool shd = args.shadow_hits != nullptr;  // fused shadow rays (no timeline build of that one)
-    const bool pairs = args.pairs != nullptr && !args.count_nodes;  // two levels per load (static trees)
-    auto kern = shd ? (args.count_nodes ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, true, false>
-                                        : (pairs ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, true, true>
-                                                 : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, true, false>))
+    auto kern = shd ? (args.count_nodes ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, true>
+                                        : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, true>)
                     : (args.count_nodes
-                           ? (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, true, false, false>
-                                         : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, false, false>)
-                           : (args.debug ? (pairs ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false, true>
-                                                  : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false, false>)
-                                         : (pairs ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false, true>
-                                                  : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false, false>)));
+                           ? (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, true, false>
+                                         : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, false>)
+                           : (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false>
+                                         : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false>));
     size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
                                 (args.count_nodes ? (kStackBlock / 64) * kCountQueue + kSatTags : 0)) * sizeof(uint32_t);
     // cached per context (= per device): [deep stack?][fused shadows?][counting instantiation?]
-    int &blocks_per_cu = li.occupancy[(args.debug ? 16 : 0) + (pairs ? 8 : 0) + (NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
+    int &blocks_per_cu = li.occupancy[(args.debug ? 16 : 0) + (NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
     if (blocks_per_cu == 0) {
         int n = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kStackBlock, lds_bytes);
@@ -1815,6 +1391,7 @@ hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t
     }
     // li.counters = {8 claim counters (128 B apart), deferred-ray count, deferred items}: zero when a frame
     // starts (armed at allocation and re-armed by the last kernel of the previous frame)
+    if (li.dual) return launch_trace_dual(args, li, stream);
     const bool ge = (args.u.flags & SVO_F_MISC_BOOL) != 0;
     if (li.deep_stack)  // trees deeper than kTopLevels + 1 + kStackLevels: more LDS per workgroup, fewer resident waves
         return ge ? launch_stack<true, kStackLevelsDeep>(args, li, stream) : launch_stack<false, kStackLevelsDeep>(args, li, stream);

@@ -8,7 +8,7 @@ from conftest import GOLDEN, assert_hits_equal, set_uniforms_from_oracle
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [0, 1]  # RESTART, STACK
+VARIANTS = [0, 1, 2]  # RESTART, STACK (two rays per lane where eligible), STACK1 (one ray per lane)
 
 
 def _render(pkg, gpu, words, u, variant, capacity=None, tile=None):
