@@ -35,10 +35,18 @@ int main(int argc, char **argv) {
             mg.render(r).update(svo::Settings{}, svo::Character{});
         }
         std::vector<svo_hit> sharded(size_t(W) * H), whole(size_t(W) * H);
-        for (int frame = 0; frame < 3; frame++) mg.frame();  // (frames queue up behind each other on the streams)
+        // three frames queue up behind each other on the streams, each from a different camera: a frame whose records were
+        // overwritten while the previous frame's gather still read them, or that kept stale ones, differs from the check below
+        svo::Character cam;
+        for (int frame = 0; frame < 3; frame++) {
+            cam.pos[0] = 0.1f + 0.35f * float(frame);
+            cam.look[0] = -0.2f * float(frame);
+            for (int r = 0; r < n; r++) mg.render(r).update(svo::Settings{}, cam);
+            mg.frame();
+        }
         mg.read_frame(sharded.data());
         mg.sync();
-        mg.render(0).render_host(whole.data());
+        mg.render(0).render_host(whole.data());  // the last camera, unsharded
         const bool same = !std::memcmp(sharded.data(), whole.data(), whole.size() * sizeof(svo_hit));
         size_t hits = 0;
         for (const svo_hit &h : whole) hits += (h.steps_depth_hit >> 16) & 1;

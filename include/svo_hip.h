@@ -88,16 +88,17 @@ typedef struct svo_ctx svo_ctx;
 
 /* kernel variants (svo_set_option SVO_OPT_VARIANT) */
 #define SVO_VARIANT_RESTART 0 /* reference-shaped: float-compare descent from the root every step */
-#define SVO_VARIANT_STACK 1   /* integer path codes + per-ray ancestor stack in LDS + LDS top table + refill (default).  Static trees
-                                 (pause_adaptive, or caller-supplied rays) of depth <= 16 without fused shadow rays are traced with TWO
-                                 rays per lane -- one ray's dependent load travels while the lane's other ray steps -- over a
-                                 device-built table with one word per node word (its child group and which of the 8 children are
-                                 empty leaves: a step into an empty leaf needs no load).  The table costs as much device memory as
-                                 the node buffer and is rebuilt by the first such trace after the words changed (one pass over the
-                                 array, one host synchronisation); arrays whose child groups are not 8-aligned inside the buffer
-                                 (Octree::subdivide always makes them so, octree.rs:72-90) and every other mode run one ray per lane.
-                                 Results do not depend on which kernel runs. */
-#define SVO_VARIANT_STACK1 2  /* the same, always one ray per lane (no table) */
+#define SVO_VARIANT_STACK 1   /* integer path codes + per-ray ancestor stack in LDS + LDS top table + refill (default) */
+/* Two experiments of round 3, kept selectable and under the same parity tests (neither is faster on the benchmark
+ * frame -- the traversal is bound by instruction issue, not by its dependent loads).  Both walk a device-built table with one word
+ * per node word (its child group and which of the 8 children are empty leaves, so a step into an empty leaf needs no load; as much
+ * device memory as the node buffer, rebuilt by the first such trace after the words changed: one pass over the array and one host
+ * synchronisation) and apply to static trees (pause_adaptive, or caller-supplied rays); arrays whose child groups are not
+ * 8-aligned inside the buffer (Octree::subdivide always makes them so, octree.rs:72-90) and every other mode run SVO_VARIANT_STACK.
+ * Results do not depend on the variant. */
+#define SVO_VARIANT_ETAB 2    /* the STACK kernel over that table: half the dependent loads */
+#define SVO_VARIANT_DUAL 3    /* two rays per lane, software-pipelined: one ray's load travels while the lane's other ray steps
+                                 (trees of depth <= 16, no fused shadow rays; otherwise as SVO_VARIANT_ETAB) */
 
 typedef enum svo_option {
     SVO_OPT_VARIANT = 0,
@@ -122,7 +123,7 @@ typedef enum svo_option {
                                    2 (default) = automatic, which fuses whenever the sun direction is one the fast arithmetic covers
                                    (1080p: 0.65 -> 0.58 ms, 4K: 2.04 -> 1.78 ms on the benchmark tree).  The image is the same either way. */
     SVO_OPT_PAIR_TABLE = 13, /* accepted and ignored: the two-levels-per-load table of round 2 measured a net loss and left the library;
-                                the child-mask table of SVO_VARIANT_STACK took its place */
+                                the child-mask table of SVO_VARIANT_ETAB took its place */
     SVO_OPT_CULL = 14,       /* pixel frames, STACK variant: 64-pixel blocks whose rays all miss the cube (decided conservatively from
                                 the block's corner rays) get their all-zero records from a pre-pass and are never claimed by the
                                 trace.  0 off, 1 whenever the camera is outside the cube, 2 (default) when in addition at least 40 % of a
@@ -267,6 +268,11 @@ int svo_timing_collect(svo_ctx *ctx, float *ms_out, size_t cap, size_t *n_out);
 /* Diagnostic for profiling: n_loads single-dword buffer loads over the node buffer, lane i at byte i * stride_bytes
  * (the trace kernels' access shape), to calibrate hardware byte counters on a known line count. */
 int svo_diag_gather(svo_ctx *ctx, uint32_t stride_bytes, uint32_t n_loads);
+
+/* Diagnostic for the tests of the culling pass (SVO_OPT_CULL): the class byte of each of the first n_strips 64-pixel blocks of
+ * the last pixel frame that ran the pass (block b of a width x height rectangle, 8x8 blocks row-major; 0xFF = culled: the pass
+ * wrote the block's all-zero records and the trace never claimed it).  Blocking; SVO_ERR_STATE when that frame ran without it. */
+int svo_diag_strip_classes(svo_ctx *ctx, uint8_t *host_out, size_t n_strips);
 
 /* Counter scan (compute.wgsl).  Lists hold `capacity` words: slot 0 = count, slots 1.. = indices. */
 int svo_scan_dispatch(svo_ctx *ctx, uint32_t node_length);

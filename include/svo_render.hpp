@@ -321,6 +321,10 @@ class MultiGpuFrame {
         const size_t rec = size_t(n_pad_) * tw_ * th_;
         std::vector<const void *> send(world_);
         for (uint32_t r = 0; r < world_; r++) {
+            // the previous frame's gather may still be reading wire_[r] on this rank's communication stream: this frame's
+            // trace and pack, which overwrite hits_[r] / wire_[r], are ordered behind it (svo_hip.h: svo_gather_wait before
+            // `send` is overwritten)
+            check(svo_gather_wait(ctxs_[r]));
             renders_[r]->render_tiles(tw_, th_, r, world_, hits_[r]);
             check(svo_pack_records(ctxs_[r], hits_[r], rec, wire_[r]));
             send[r] = wire_[r];

@@ -42,7 +42,7 @@ DEVICE_SYMBOLS = [
     "svo_nodes_alloc", "svo_nodes_bind_device", "svo_nodes_write", "svo_nodes_scatter", "svo_nodes_read", "svo_nodes_device_ptr", "svo_nodes_share", "svo_nodes_invalidate",
     "svo_comm_unique_id", "svo_comm_init_rank", "svo_comm_init_all", "svo_comm_destroy", "svo_gather_frame", "svo_gather_frame_all", "svo_gather_wait",
     "svo_set_uniforms", "svo_render", "svo_render_host", "svo_render_tiles", "svo_render_secondary", "svo_render_tiles_secondary", "svo_assemble_tiles", "svo_assemble_tiles_packed", "svo_assemble_tiles_rgba", "svo_pack_records", "svo_trace_rays",
-    "svo_last_render_ms", "svo_timing_collect", "svo_diag_gather", "svo_scan_dispatch", "svo_scan_read",
+    "svo_last_render_ms", "svo_timing_collect", "svo_diag_gather", "svo_diag_strip_classes", "svo_scan_dispatch", "svo_scan_read",
 ]
 HOST_SYMBOLS = [
     "svo_cpu_octree_new", "svo_cpu_octree_free", "svo_cpu_octree_len", "svo_cpu_octree_load_file",
@@ -121,6 +121,7 @@ def lib():
     sig("svo_last_render_ms", C.c_int, vp, fp)
     sig("svo_timing_collect", C.c_int, vp, fp, sz, C.POINTER(sz))
     sig("svo_diag_gather", C.c_int, vp, u32, u32)
+    sig("svo_diag_strip_classes", C.c_int, vp, vp, sz)
     sig("svo_scan_dispatch", C.c_int, vp, u32)
     sig("svo_scan_read", C.c_int, vp, vp, C.POINTER(u32), vp, C.POINTER(u32), sz)
     # host data model (include/svo_host.h)

@@ -220,14 +220,17 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     const bool debug_hits = (ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE) && (ctx->uniforms.flags & SVO_F_SHOW_HITS);
     const bool stack = want_stack && !debug_hits;
     a.shadow_hits = stack ? opt.shadow_out : nullptr;
-    // two rays per lane over the E table (svo_dual.hip): static trees, no fused shadow rays, trees the default stack resolves
+    // SVO_VARIANT_ETAB / SVO_VARIANT_DUAL (experiments of round 3): static trees walked through the E table
+    // (svo_dual.hip: child group + which children are empty leaves), by the one-ray kernel or by the two-rays-per-lane kernel
     bool dual = false;
-    if (stack && !counting && !a.shadow_hits && ctx->variant == SVO_VARIANT_STACK && ctx->tree_depth <= (uint32_t)svo::dual_max_depth()) {
-        rc = ensure_etab(ctx, &dual);
+    if (stack && !counting && (ctx->variant == SVO_VARIANT_ETAB || ctx->variant == SVO_VARIANT_DUAL)) {
+        bool ok = false;
+        rc = ensure_etab(ctx, &ok);
         if (rc) return rc;
-        if (dual) {
+        if (ok) {
             a.etab = ctx->store->etab;
             a.top_table = ctx->store->etop;
+            dual = ctx->variant == SVO_VARIANT_DUAL && !a.shadow_hits && ctx->tree_depth <= (uint32_t)svo::dual_max_depth();
         }
     }
     const uint32_t n_strips = (wd.n_items + 63u) / 64u;
@@ -648,7 +651,7 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
     if (!ctx) return SVO_ERR_ARG;
     switch (option) {
         case SVO_OPT_VARIANT:
-            if (value != SVO_VARIANT_RESTART && value != SVO_VARIANT_STACK && value != SVO_VARIANT_STACK1) return fail(ctx, SVO_ERR_ARG, "unknown variant");
+            if (value != SVO_VARIANT_RESTART && value != SVO_VARIANT_STACK && value != SVO_VARIANT_ETAB && value != SVO_VARIANT_DUAL) return fail(ctx, SVO_ERR_ARG, "unknown variant");
             ctx->variant = (int)value;
             return SVO_OK;
         case SVO_OPT_TIMING: {
@@ -827,9 +830,12 @@ int svo_nodes_write(svo_ctx *ctx, size_t word_offset, const uint32_t *host_words
         return fail(ctx, SVO_ERR_ARG, "write past the node buffer capacity");
     int rc = bind(ctx);
     if (rc) return rc;
-    if (n)
+    if (n) {
+        rc = order_after_last_write(ctx);  // a shared store: writes land in the order they were issued, whichever context issued them
+        if (rc) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(ctx->nodes + word_offset, host_words, n * sizeof(uint32_t), hipMemcpyHostToDevice,
                                     ctx->stream));
+    }
     return note_write(ctx, true);
 }
 
@@ -841,6 +847,8 @@ int svo_nodes_scatter(svo_ctx *ctx, const uint32_t *indices, const uint32_t *hos
         if (indices[i] >= ctx->capacity) return fail(ctx, SVO_ERR_ARG, "scatter index past the node buffer capacity");
     int rc = bind(ctx);
     if (rc || n == 0) return rc;
+    rc = order_after_last_write(ctx);  // a shared store: writes land in the order they were issued, whichever context issued them
+    if (rc) return rc;
     rc = ensure_dev(ctx, &ctx->scatter_buf, &ctx->scatter_bytes, 2 * n * sizeof(uint32_t));
     if (rc) return rc;
     uint32_t *d_idx = (uint32_t *)ctx->scatter_buf, *d_val = d_idx + n;
@@ -858,6 +866,8 @@ int svo_nodes_read(svo_ctx *ctx, size_t word_offset, uint32_t *host_words, size_
     int rc = bind(ctx);
     if (rc) return rc;
     if (n) {
+        rc = order_after_last_write(ctx);  // (a write another context of a shared store has enqueued is read, not raced)
+        if (rc) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(host_words, ctx->nodes + word_offset, n * sizeof(uint32_t), hipMemcpyDeviceToHost,
                                     ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1035,6 +1045,18 @@ int svo_diag_gather(svo_ctx *ctx, uint32_t stride_bytes, uint32_t n_loads) {
     return SVO_OK;
 }
 
+int svo_diag_strip_classes(svo_ctx *ctx, uint8_t *host_out, size_t n_strips) {
+    if (!ctx || (!host_out && n_strips)) return SVO_ERR_ARG;
+    const svo_ctx::Sched &sc = ctx->sched[0];
+    if (!sc.cls_now || !sc.order_filtered) return fail(ctx, SVO_ERR_STATE, "the last pixel frame was traced without a culling pass");
+    if (n_strips > sc.cap) return fail(ctx, SVO_ERR_ARG, "more strips than the last frame had");
+    int rc = bind(ctx);
+    if (rc || n_strips == 0) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(host_out, sc.cls_now, n_strips, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SVO_OK;
+}
+
 int svo_scan_dispatch(svo_ctx *ctx, uint32_t node_length) {
     if (!ctx) return SVO_ERR_ARG;
     if (!ctx->nodes) return fail(ctx, SVO_ERR_STATE, "svo_nodes_alloc not called");
@@ -1052,6 +1074,8 @@ int svo_scan_dispatch(svo_ctx *ctx, uint32_t node_length) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->scan_unsub, 0, sizeof(uint32_t), ctx->stream));
     }
     uint32_t n = node_length < ctx->capacity ? node_length : (uint32_t)ctx->capacity;
+    rc = order_after_last_write(ctx);  // (the scan reads -- and with SCAN_CLEARS_COUNTERS writes -- the words of a possibly shared store)
+    if (rc) return rc;
     HIP_TRY(ctx, svo::launch_scan(ctx->nodes, n, node_length, ctx->scan_sub, ctx->scan_unsub,
                                   (uint32_t)ctx->scan_capacity, ctx->scan_clears, ctx->stream));
     return SVO_OK;

@@ -5,7 +5,7 @@ import ctypes as C
 from ._lib import SvoError, lib
 
 OPT_VARIANT, OPT_TIMING, OPT_GRID_BLOCKS, OPT_REFILL_MIN, OPT_STRIP_ITEMS, OPT_DYNAMIC_STRIPS, OPT_PRIO_STEPS, OPT_DEBUG_BUFFER, OPT_SCHEDULE, OPT_TREE_DEPTH, OPT_BLOCK_SHAPE, OPT_SCAN_CLEARS_COUNTERS, OPT_FUSED_SHADOWS, OPT_PAIR_TABLE, OPT_CULL, OPT_CAMERA_SHORTCUT, OPT_SCHEDULE_MOTION = range(17)
-VARIANT_RESTART, VARIANT_STACK, VARIANT_STACK1 = 0, 1, 2
+VARIANT_RESTART, VARIANT_STACK, VARIANT_ETAB, VARIANT_DUAL = 0, 1, 2, 3
 
 
 class Gpu:
@@ -48,6 +48,13 @@ class Gpu:
         ms = C.c_float()
         self.check(lib().svo_last_render_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def strip_classes(self, n_strips):
+        """class byte per 64-pixel block of the last pixel frame that ran the culling pass (0xFF = culled); diagnostics"""
+        import numpy as np
+        out = np.zeros(n_strips, dtype=np.uint8)
+        self.check(lib().svo_diag_strip_classes(self._h, out.ctypes.data_as(C.c_void_p), n_strips))
+        return out
 
     def timing_collect(self, cap=65536):
         """durations (ms) of the trace launches recorded since the last collect"""

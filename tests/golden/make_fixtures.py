@@ -22,7 +22,8 @@ REF = "/root/reference/files"
 
 
 def main():
-    for name in ("small", "monu9"):
+    # (monu10, defualt, phantom_mansion: their voxel lists pin the loader restatement through the node counts of SURVEY.md 8c KAT 3)
+    for name in ("small", "monu9", "monu10", "defualt", "phantom_mansion"):
         data = open(os.path.join(REF, name + ".vox"), "rb").read()
         size, xyzi, pal = O.vox_parse(data)
         words = O.Tree.from_vox(data).to_octree()

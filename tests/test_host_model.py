@@ -36,7 +36,7 @@ def test_no_device_is_reported_not_crashed(pkg):
         pkg.Gpu(0)
 
 
-@pytest.mark.parametrize("name", ["small", "monu9"])
+@pytest.mark.parametrize("name", ["small", "monu9", "monu10", "defualt", "phantom_mansion"])
 def test_vox_to_node_words_matches_oracle(pkg, O, name):
     size, xyzi, pal, n, _ = load_vox_fixture(name)
     ours = pkg.CpuOctree.from_voxels(size, xyzi, pal)

@@ -40,6 +40,36 @@ def test_node_counts_from_assets(O):
         assert solid == n_vox  # every voxel of the model is one solid leaf
 
 
+def test_node_counts_of_the_other_assets(O):
+    """KAT 3, the rest: the node counts SURVEY.md 8c computed independently from the .vox files under the load_vox rules
+    (cpu_octree.rs:177-210) -- monu10 194 856, defualt 108 088, phantom_mansion 1 132 944 words -- and a full 16^3 block:
+    8 * (1 + 8 + 64 + 512) = 4 680 words."""
+    for name, n_vox, n_words in (("monu10", 150764, 194856), ("defualt", 56784, 108088), ("phantom_mansion", 631021, 1132944)):
+        size, xyzi, pal, n, crc = load_vox_fixture(name)
+        assert xyzi.shape[0] == n_vox and n == n_words
+        words = O.Tree.from_voxels(size, xyzi, pal).to_octree()
+        assert words.size == n_words
+        assert int(np.bitwise_xor.reduce(words * np.arange(1, words.size + 1, dtype=np.uint32))) == crc
+        # every voxel of the model is one leaf; a voxel whose palette colour is black encodes as VOXEL_OFFSET + 0, the empty
+        # leaf (octree.rs:28-35: the reference cannot tell the two apart either) -- phantom_mansion has 101 of them
+        black = int(((pal[(xyzi[:, 3].astype(np.int64) - 1) & 255] & 0xFFFFFF) == 0).sum())
+        assert ((words >> 4) > O.VOXEL_OFFSET).sum() == n_vox - black and black == (101 if name == "phantom_mansion" else 0)
+    g = np.arange(16, dtype=np.uint8)
+    x, y, z = np.meshgrid(g, g, g, indexing="ij")
+    full = np.stack([x.ravel(), y.ravel(), z.ravel(), np.ones(4096, dtype=np.uint8)], axis=1)
+    pal = np.full(256, 0xFF3366CC, dtype=np.uint32)
+    words = O.Tree.from_voxels(16, full, pal).to_octree()
+    assert words.size == 4680 and ((words >> 4) > O.VOXEL_OFFSET).sum() == 4096 and ((words >> 4) < O.VOXEL_OFFSET).sum() == 584
+
+
+def test_hand_derived_rays(O):
+    """tests/kat_cases.py: two-level descent, three- and two-axis ties, a start on a centre plane under both tie-break modes,
+    the 100 / 101 step boundary for hits and for rays that leave the cube -- every record derived on paper from the WGSL."""
+    import kat_cases as K
+    for name, words, flags, rays, expected in K.cases():
+        K.check(O.trace_rays(words, rays, flags=flags), expected, name)
+
+
 def test_single_level_rays(O):
     """KATs 4-6: tree with only child 7 solid."""
     words = np.array([0x80000000] * 7 + [0x8FF00000], dtype=np.uint32)

@@ -8,7 +8,7 @@ from conftest import GOLDEN, assert_hits_equal, set_uniforms_from_oracle
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [0, 1, 2]  # RESTART, STACK (two rays per lane where eligible), STACK1 (one ray per lane)
+VARIANTS = [0, 1, 2, 3]  # RESTART, STACK, and the two experiments over the child-mask table: ETAB (one ray per lane), DUAL (two)
 
 
 def _render(pkg, gpu, words, u, variant, capacity=None, tile=None):
@@ -142,6 +142,23 @@ def test_known_answers_single_level(pkg, gpu, O):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
+def test_hand_derived_known_answers(pkg, gpu, O, variant):
+    """tests/kat_cases.py on the device, through svo_trace_rays: the records derived on paper from the WGSL (two-level descent,
+    multi-axis ties, a start on a centre plane under both tie-break modes, the 100 / 101 step boundary) -- the same literals the
+    oracle is pinned with."""
+    import torch
+    import kat_cases as K
+    gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+    for name, words, flags, rays, expected in K.cases():
+        render = pkg.Render(gpu, (8, 8), words, capacity=max(words.size, 64))
+        render.uniforms.flags = flags
+        render.upload_uniforms()
+        h = pkg.render.hits_to_numpy(render.trace_rays(torch.from_numpy(rays).cuda()))
+        gpu.sync()
+        K.check(h, expected, f"{name} (variant {variant})")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_step_limit_and_malformed(pkg, gpu, O, variant):
     """>100 steps sentinel (shader.wgsl:242-244) and a malformed array (zero words = a pointer cycle):
     the kernel must terminate and report the sentinel like the oracle."""
@@ -150,11 +167,11 @@ def test_step_limit_and_malformed(pkg, gpu, O, variant):
     assert (want["value"] == 0xFF000000).any(), "fixture should contain step-limit rays"
     words = np.zeros(64, dtype=np.uint32)  # every word is 'interior -> group 0'
     u = O.make_uniforms(width=64, height=64, flags=O.F_PAUSE_ADAPTIVE)
-    if variant == 1:
-        # STACK resolves 24 levels; deeper trees are refused loudly (the oracle's guard is at depth 31)
+    if variant >= 1:
+        # the STACK kernels resolve 16 (24) levels; deeper trees are refused loudly (the oracle's guard is at depth 31)
         render = pkg.Render(gpu, (64, 64), words, capacity=64)
         set_uniforms_from_oracle(render, u)
-        gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+        gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
         hits = render.render()
         with pytest.raises(pkg.SvoError):
             gpu.sync()
@@ -164,6 +181,108 @@ def test_step_limit_and_malformed(pkg, gpu, O, variant):
     else:
         got = _render(pkg, gpu, words, u, 0)
         assert_hits_equal(got, O.trace_frame(words, u, threads=2), "malformed array")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_unaligned_child_groups(pkg, gpu, O, variant):
+    """A node array whose child groups are not 8-aligned (nothing in the layout forbids it, LAYOUT.md; Octree::subdivide
+    never makes one): the child-mask table of the ETAB / DUAL variants cannot name such groups, its builder says so and
+    the general kernel traces -- same records as the oracle either way."""
+    V = 134217728
+    words = np.zeros(64, dtype=np.uint32)
+    words[0:8] = (V + 0) << 4                    # root group: empty leaves ...
+    words[3] = 12 << 4                           # ... except child 3 -> a group at word 12 (unaligned)
+    words[6] = (V + 0x00FF00) << 4               # and a solid child
+    words[12:20] = [(V + (0x10 * (i + 1) if i % 3 == 0 else 0)) << 4 for i in range(8)]
+    words[17] = 28 << 4                          # one level further down, unaligned again
+    words[28:36] = [(V + (0x2000 + i if i % 2 else 0)) << 4 for i in range(8)]
+    seen = set()
+    for pos, look in (((0.1, 0.2, -1.5), (0.0, 0.0, 1.5)), ((0.3, -0.4, 0.2), (0.5, 0.7, -0.3)), ((-1.8, 1.1, 0.4), (1.0, -0.6, -0.2))):
+        u = O.make_uniforms(pos=pos, look=look, width=96, height=64, flags=O.F_PAUSE_ADAPTIVE)
+        got = _render(pkg, gpu, words, u, variant)
+        want = O.trace_frame(words, u, threads=2)
+        seen |= set(np.unique(want["value"]).tolist())
+        assert_hits_equal(got, want, f"unaligned child groups, pose {pos}")
+    assert {6, 12, 29} <= seen, "the poses should hit leaves of all three groups"
+
+
+CULL_POSES = [  # (pos, look): all outside the cube
+    ((0.2, 0.1, -1.2), (0.0, 0.0, 1.0)),            # close: the cube fills most of the frame
+    ((0.3, 0.2, -3.0), (0.0, 0.0, 1.0)),            # a cube with sky all around
+    ((2.5, 1.5, -6.0), (-0.4, -0.25, 1.0)),         # far
+    ((10.0, 8.0, -30.0), (-0.31, -0.25, 1.0)),      # very far: the cube covers a few blocks
+    ((0.0, 1.0005, -2.0), (0.0, 0.0, 1.0)),         # grazing the face y = 1: rays nearly parallel to it, just above
+    ((0.0, 1.3, -2.0), (0.0, -0.02, 1.0)),          # looking along the top face from slightly above
+    ((2.0, 2.0, -2.0), (-1.0, -1.0, 1.0)),          # a cube corner pointing at the camera (three faces, six silhouette edges)
+    ((2.0, 2.0, -2.0), (-1.0, -0.62, 1.0)),         # the same corner near the frame's edge: partly visible cube
+    ((1.5, 0.0, 0.0), (1.0, 0.0, 0.0)),             # looking away from the cube, which lies close behind: every ray misses it (no single
+                                                    # side plane of a block's cone separates it: blocks are not culled, records still zero)
+    ((6.0, 0.5, 0.0), (1.0, 0.1, 0.0)),             # the same from further away
+]
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_culling_pass_forced(pkg, gpu, O, monu9_words, variant):
+    """SVO_OPT_CULL = 1: the pre-trace pass that writes the all-zero records of 64-pixel blocks whose rays all miss the cube
+    (ray_box_dist returns 0, shader.wgsl:66-80,197-205) and keeps them out of the trace -- the one place where a wrong decision
+    would fabricate output.  Whole frames against the oracle: camera outside at several distances, grazing a face, a corner on
+    the silhouette, odd frame sizes with partial blocks, sub-rectangles, tile sharding, shaded frames (the pass also zeroes
+    t_current / shadow records); and the decisions themselves: every culled block's oracle records are 'never entered'."""
+    gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+    gpu.set_option(pkg.gpu.OPT_CULL, 1)
+    try:
+        culled_total = 0
+        for W, H in ((256, 144), (250, 131), (67, 45)):
+            for pos, look in CULL_POSES:
+                u = O.make_uniforms(pos=pos, look=look, width=W, height=H, flags=O.F_PAUSE_ADAPTIVE)
+                want = O.trace_frame(monu9_words, u, threads=8)
+                got = _render(pkg, gpu, monu9_words, u, variant).reshape(H, W)
+                assert_hits_equal(got, want, f"cull forced, {W}x{H}, pose {pos}")
+                # the decisions of the second of _render's two frames
+                bpr, bpc = (W + 7) // 8, (H + 7) // 8
+                cls = gpu.strip_classes(bpr * bpc).reshape(bpc, bpr)
+                never = (want["value"] == 0) & ((want["info"] & 0xFF) == 0) & (((want["info"] >> 16) & 1) == 0)
+                for by, bx in np.argwhere(cls == 0xFF):
+                    assert never[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8].all(), f"block ({bx},{by}) was culled but a ray of it enters the cube"
+                culled_total += int((cls == 0xFF).sum())
+        assert culled_total > 1000, "the pass should have culled blocks on these poses"
+        # sub-rectangles and tile sharding (svo_render_tiles: the pass works per tile rectangle)
+        W, H = 256, 144
+        u = O.make_uniforms(pos=(0.3, 0.2, -3.0), look=(0.0, 0.0, 1.0), width=W, height=H, flags=O.F_PAUSE_ADAPTIVE)
+        full = O.trace_frame(monu9_words, u, threads=8)
+        render = pkg.Render(gpu, (W, H), monu9_words, capacity=monu9_words.size)
+        set_uniforms_from_oracle(render, u)
+        for tile in [(3, 5, 61, 37), (96, 40, 90, 77), (255, 143, 1, 1), (0, 7, 256, 1)]:
+            buf = render.alloc_hits(tile[2] * tile[3])
+            buf.fill_(-1)
+            got = pkg.render.hits_to_numpy(render.render(hits=buf, tile=tile))
+            gpu.sync()
+            x0, y0, w, h = tile
+            assert_hits_equal(got, full[y0:y0 + h, x0:x0 + w], f"cull forced, rect {tile}")
+        tw, th, ranks = 64, 8, 3
+        frame = np.zeros((H, W), dtype=pkg.HIT_DTYPE)
+        for r in range(ranks):
+            got = pkg.render.hits_to_numpy(render.render_tiles(tw, th, r, ranks)).reshape(-1, th, tw)
+            gpu.sync()
+            for k in range(got.shape[0]):
+                ty, tx = divmod(r + k * ranks, W // tw)
+                frame[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = got[k]
+        assert_hits_equal(frame, full, "cull forced, tile-sharded frame")
+        # shaded frames with shadow rays, fused into the primary launch and as a second launch
+        for fused in (1, 0):
+            gpu.set_option(pkg.gpu.OPT_FUSED_SHADOWS, fused)
+            for pos, look in (CULL_POSES[1], CULL_POSES[6]):
+                us = O.make_uniforms(pos=pos, look=look, width=240, height=136, flags=O.F_PAUSE_ADAPTIVE | O.F_SHADOWS)
+                rs = pkg.Render(gpu, (240, 136), monu9_words, capacity=monu9_words.size)
+                set_uniforms_from_oracle(rs, us)
+                for _ in range(2):
+                    hits, img = rs.render_host(rgba=True)
+                assert_hits_equal(hits, O.trace_frame(monu9_words, us, threads=8), f"cull forced, shaded, fused={fused}")
+                want8 = np.floor(np.clip(O.shade_frame(monu9_words, us, threads=8), 0, 1) * 255.0 + 0.5).astype(np.int32)
+                assert np.abs(img.astype(np.int32) - want8).max() <= 1
+    finally:
+        gpu.set_option(pkg.gpu.OPT_CULL, 2)
+        gpu.set_option(pkg.gpu.OPT_FUSED_SHADOWS, 2)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

@@ -59,11 +59,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="2,3,5")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--variant", type=int, default=1, help="1 STACK, 2 ETAB, 3 DUAL (svo_hip.h)")
     a = ap.parse_args()
     pkg, O = entry.load_package(), entry.load_oracle()
     import torch
     gpu = pkg.Gpu(0)
-    gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+    gpu.set_option(pkg.gpu.OPT_VARIANT, a.variant)
     want = [int(c) for c in a.configs.split(",")]
     golden = os.path.join(ROOT, "tests", "golden")
 
