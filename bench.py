@@ -70,7 +70,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="terrain16_1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: terrain16_1080p (BASELINE.json's metric) on one GPU; terrain16_4k on several -- the frame the "
+                         "1 -> 8 GPU target of BASELINE.json refers to (the 1080p frame of the same scene is then under config.also)")
     ap.add_argument("--tile-w", type=int, default=64)
     ap.add_argument("--tile-h", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -117,6 +119,8 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     pipelined = world > 1 or a.force_pipeline
+    if a.workload is None:
+        a.workload = "terrain16_4k" if world > 1 else "terrain16_1080p"
     if pipelined:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:  # only the single-process validation mode gets here without a launcher
@@ -183,13 +187,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def frame_loop(W, H):
-        """(step, drain) for W x H frames of the scene on the lanes above"""
+    def frame_loop(W, H, wire, serial_one_gpu=False):
+        """(step, drain) for W x H frames of the scene on the lanes above; wire: what the frame-end gather of a sharded frame
+        carries; serial_one_gpu: this rank traces the whole frame alone on lane 0 (the one-GPU reference of an N > 1 run)"""
         for _, r, _ in lanes:
             r.resize((W, H))
             r.update(pkg.Settings(fov=90.0), pkg.Character(cam, look))
         n_rays = W * H
-        if not pipelined and len(lanes) > 1:
+        if not pipelined and len(lanes) > 1 and not serial_one_gpu:
             bufs = [r.alloc_hits(n_rays) for _, r, _ in lanes]
             counter = [0]
 
@@ -199,7 +204,7 @@ def main():
                 lanes[k][1].render(hits=bufs[k])
                 return bufs[k]
             return step, None
-        if not pipelined:
+        if not pipelined or serial_one_gpu:
             hits = render.alloc_hits(n_rays)
 
             def step():
@@ -208,7 +213,7 @@ def main():
             return step, None
         assert W % tw == 0 and H % th == 0
         # frame i's RCCL gather overlaps frame i+1's trace (double-buffered); rank 0 un-permutes each frame
-        if a.backend == "nccl" and a.wire == "rgba8":
+        if a.backend == "nccl" and wire == "rgba8":
             n_pad_c = pkg.sharding.padded_tile_count(W, H, tw, th, world)
             recs = [r.alloc_hits(n_pad_c * tw * th) for _, r, _ in lanes]  # this rank's records stay here
             traces = [(lambda buf, r=r, h=h: r.render_tiles(tw, th, rank, world, hits=h, rgba=buf)) for (_, r, _), h in zip(lanes, recs)]
@@ -220,36 +225,45 @@ def main():
         elif a.backend == "nccl":
             traces = [(lambda buf, r=r: r.render_tiles(tw, th, rank, world, hits=buf)) for _, r, _ in lanes]
             assemble = [(lambda g, out, r=r: r.assemble_tiles(g, tw, th, out=out)) for _, r, _ in lanes]
-            pack = [(lambda rec, wire, r=r: r.pack_records(rec, wire)) for _, r, _ in lanes] if a.wire == "packed12" else None
+            pack = [(lambda rec, w12, r=r: r.pack_records(rec, w12)) for _, r, _ in lanes] if wire == "packed12" else None
             gather = [((lambda send, recv, g=g: g.gather_frame(send, recv, 0)), g.gather_wait) for g, _, _ in lanes] \
                 if gather_mode == "abi" else None
             pipe = pkg.sharding.FramePipeline(traces, W, H, tw, th, rank, world, f"cuda:{local_rank}",
                                               streams=[s for _, _, s in lanes], assemble=assemble, pack=pack, gather=gather)
         else:
+            # validation mode (gloo): ranks share the visible GPUs, the gather is staged through host memory
             n_pad_v = pkg.sharding.padded_tile_count(W, H, tw, th, world)
+            colour = wire == "rgba8"
 
             def via_host(r):
-                dev_buf = torch.zeros((n_pad_v, th * tw, 4), dtype=torch.int32, device=f"cuda:{local_rank}")
+                dev_rec = torch.zeros((n_pad_v, th * tw, 4), dtype=torch.int32, device=f"cuda:{local_rank}")
+                dev_col = torch.zeros((n_pad_v, th * tw, 1), dtype=torch.int32, device=f"cuda:{local_rank}") if colour else None
 
                 def trace(buf):
-                    r.render_tiles(tw, th, rank, world, hits=dev_buf)
-                    buf.copy_(dev_buf)  # blocking D2H on the lane's stream: validation only
+                    if colour:
+                        r.render_tiles(tw, th, rank, world, hits=dev_rec, rgba=dev_col)
+                        buf.copy_(dev_col)
+                    else:
+                        r.render_tiles(tw, th, rank, world, hits=dev_rec)
+                        buf.copy_(dev_rec)  # blocking D2H on the lane's stream: validation only
                 return trace
 
             pipe = pkg.sharding.FramePipeline([via_host(r) for _, r, _ in lanes], W, H, tw, th, rank, world, "cpu",
-                                              streams=[s for _, _, s in lanes], pack=True if a.wire == "packed12" else None)
+                                              streams=[s for _, _, s in lanes], pack=True if wire == "packed12" else None,
+                                              words=1 if colour else 4)
         return pipe.step, pipe.drain
 
-    def measure(W, H, steps, warmup):
+    def measure(W, H, steps, warmup, wire, serial_one_gpu=False):
         """K timed frames: (elapsed s [max over ranks], kernel ms of the K launches, last frame)"""
-        step, drain = frame_loop(W, H)
+        step, drain = frame_loop(W, H, wire, serial_one_gpu)
+        bar = torch.cuda.synchronize if serial_one_gpu else barrier  # (the one-GPU reference runs on rank 0 alone: no collective)
         for g, _, _ in lanes:
             g.set_option(pkg.gpu.OPT_TIMING, max(steps, 1))
         for _ in range(warmup):
             step()
         if drain:
             drain()
-        barrier()
+        bar()
         for g, _, _ in lanes:
             g.timing_collect()  # drop the warm-up launches' records
         t_start = time.perf_counter()
@@ -257,13 +271,13 @@ def main():
             out = step()
         if drain:
             out = drain()  # every one of the K frames is gathered and assembled inside the timed region
-        barrier()
+        bar()
         elapsed = time.perf_counter() - t_start
         # per-launch kernel durations of exactly the K timed launches: HIP event pairs recorded by the C ABI
         # around each launch on the launch stream
         kms = np.concatenate([g.timing_collect() for g, _, _ in lanes])
-        assert len(kms) == steps
-        if pipelined:
+        assert len(kms) == steps, (len(kms), steps)
+        if pipelined and not serial_one_gpu:
             t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if a.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -271,15 +285,14 @@ def main():
 
     W, H = wl["width"], wl["height"]
     n_rays = W * H
-    elapsed, kms, out = measure(W, H, a.steps, a.warmup)
+    elapsed, kms, out = measure(W, H, a.steps, a.warmup, a.wire)
     gpu.sync()
     colour_wire = pipelined and a.wire == "rgba8"
-    if colour_wire and a.backend != "nccl":
-        raise SystemExit("--wire rgba8 needs --backend nccl")
     frame = out.reshape(-1, 1 if colour_wire else 4).cpu().numpy().view(np.uint32) if rank == 0 else None
 
     # ---- beside the headline, same run, outside its timed region ----
     extras = {}
+    frame_rgba = None
     if not a.no_extras:
         k_extra = max(10, min(a.steps, 50))
         if not pipelined:
@@ -309,12 +322,40 @@ def main():
         # (3) the other frame size of the same scene and pose (the 4K frame is the one the 1 -> 8 GPU target refers to)
         other = "terrain16_4k" if a.workload == "terrain16_1080p" else "terrain16_1080p"
         ow = WORKLOADS[other]
-        e2, k2, _ = measure(ow["width"], ow["height"], k_extra, 3)
+        e2, k2, _ = measure(ow["width"], ow["height"], k_extra, 3, a.wire)
         extras["also"] = {"workload": other, "value": round(ow["width"] * ow["height"] * k_extra / e2 / 1e6, 2), "unit": "Mrays/s",
                           "steps": k_extra, "ms_per_step": round(e2 / k_extra * 1e3, 4), "kernel_avg_ms": round(float(np.mean(k2)), 4)}
         if ALGO_BYTES_PER_RAY.get(other) and not pipelined:
             extras["also"]["roofline_frac"] = round(ALGO_BYTES_PER_RAY[other] * ow["width"] * ow["height"] / (float(np.mean(k2)) * 1e-3) / 1e9
                                                     / HBM_PEAK_GBS, 5)
+        if pipelined and not colour_wire:
+            # (4) the same sharded frame with the COLOUR wire: the ranks shade their own tiles and the RGBA8 image -- what the
+            # reference displays (shader.wgsl:261-304, render.rs:246-248) -- is what travels: 4 bytes per ray instead of 12
+            e3, k3, out3 = measure(W, H, k_extra, 3, "rgba8")
+            gpu.sync()
+            frame_rgba = out3.reshape(-1, 1).cpu().numpy().view(np.uint32) if rank == 0 else None
+            extras["also_rgba8"] = {"workload": a.workload, "wire": "rgba8: 4 B/ray (shaded RGBA8 colour; records stay on the ranks)",
+                                    "value": round(n_rays * k_extra / e3 / 1e6, 2), "unit": "Mrays/s", "steps": k_extra,
+                                    "ms_per_step": round(e3 / k_extra * 1e3, 4), "kernel_avg_ms": round(float(np.mean(k3)), 4)}
+        if pipelined:
+            # (5) one GPU, the same frame, unsharded and serial (rank 0 alone, the others wait): what N GPUs are compared with
+            if rank == 0:
+                e1, k1, _ = measure(W, H, k_extra, 3, a.wire, serial_one_gpu=True)
+                extras["one_gpu_same_workload"] = {"value": round(n_rays * k_extra / e1 / 1e6, 2), "unit": "Mrays/s", "steps": k_extra,
+                                                   "ms_per_step": round(e1 / k_extra * 1e3, 4), "kernel_avg_ms": round(float(np.mean(k1)), 4),
+                                                   "what": "rank 0 traces the whole frame alone, frames serial, same run"}
+            barrier()
+            # (6) what the links allow: every ray's wire bytes end on rank 0, (N - 1) / N of them over rank 0's N - 1 inbound
+            # xGMI links, one peer per link (7 links per GPU, ~64 GB/s per link and direction sustained: DESIGN.md 7)
+            link_gbs = 64.0
+            bound = {}
+            for wname, bpr in (("packed12", 12), ("full16", 16), ("rgba8", 4)):
+                per_link = n_rays * bpr / world  # bytes one peer sends per frame
+                bound[wname] = {"bytes_into_rank0_per_frame": int(n_rays * bpr * (world - 1) // world), "bytes_per_link_per_frame": int(per_link),
+                                "min_ms_per_frame": round(per_link / (link_gbs * 1e9) * 1e3, 4),
+                                "max_mrays_s": round(n_rays / (per_link / (link_gbs * 1e9)) / 1e6, 1)}
+            extras["link_bound"] = {"assumed_gb_s_per_link_and_direction": link_gbs, "links_into_rank0": world - 1, **bound,
+                                    "note": "an upper bound at perfect link efficiency; the gathers of consecutive frames overlap the traces"}
         for _, r, _ in lanes:
             r.resize((W, H))
             r.update(pkg.Settings(fov=90.0), pkg.Character(cam, look))
@@ -333,7 +374,7 @@ def main():
                         f"{ {'packed12': '12 B/ray (wire records)', 'full16': '16 B/ray (records)', 'rgba8': '4 B/ray (shaded RGBA8 colour; records stay on the ranks)'}[a.wire] }, "
                         "overlapped with the following frames' traces")
         result = {
-            "metric": "Mrays/sec at 1920x1080, depth-16 SVO; achieved HBM GB/s vs peak",
+            "metric": "Mrays/sec at 1920x1080, depth-16 SVO; achieved HBM GB/s vs peak",  # (BASELINE.json's name; config.workload says which frame)
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
@@ -356,7 +397,7 @@ def main():
                 getattr(u, f)[:] = list(getattr(render.uniforms, f))
             u.flags, u.misc_value = render.uniforms.flags, render.uniforms.misc_value
             host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            cores = max(1, min(host_cores, 64))  # the oracle's thread pool is capped at 64
+            cores = max(1, min(host_cores, 256))  # every host core this process may use (the oracle's pool takes up to 256 threads)
             # bounded sample: the top H / cpu_frac rows... a full frame is only seconds of CPU work, so by
             # default (cpu_frac = 1) the sample is the whole frame and the byte count below is exact
             rows = H // a.cpu_frac
@@ -383,6 +424,11 @@ def main():
             else:
                 got = frame.reshape(H, W, 4)[:rows].reshape(-1, 4)
                 parity = bool(np.array_equal(got, rec.view(np.uint32).reshape(-1, 4)))
+            if extras.get("also_rgba8") is not None and frame_rgba is not None:
+                want = O.shade_frame(words, u, tile=(0, 0, W, rows), threads=cores)
+                want8 = np.floor(np.clip(want, 0, 1) * 255.0 + 0.5).astype(np.int32).reshape(-1, 4)
+                got8 = frame_rgba.reshape(H, W)[:rows].reshape(-1).view(np.uint8).reshape(-1, 4).astype(np.int32)
+                result["config"]["also_rgba8"]["image_matches_oracle_fs_main_within_1_code_value"] = bool(np.abs(got8 - want8).max() <= 1)
             cpu = {"value": round(len(rec) * reps / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores,
                    "host_cores_available": host_cores, "host_cores_total": os.cpu_count(), "kind": "port",
                    "sample": f"rows 0..{rows - 1} of the same frame ({len(rec)} rays) traced {reps} times ({cpu_s:.1f} s), "

@@ -56,7 +56,7 @@ def config4(pkg):
 
 def config5(pkg):
     """Procedural fractal, depth 20 (87 M words), 3840x2160 with 4 secondary rays per hit pixel; needs SVO_OPT_TREE_DEPTH 20."""
-    words = pkg.scenes.fractal(seed=1, max_depth=20, cam=(-0.9999, -0.9999, -0.9999), lod_c=3000.0, min_depth=4,
+    words = pkg.scenes.fractal(seed=0, max_depth=20, cam=(-0.9999, -0.9999, -0.9999), lod_c=3000.0, min_depth=4,
                                max_words=120_000_000)
     poses = [((-0.9990, -0.9985, -0.9980), (-1.0, -1.2, -0.9))]
     return words, poses, (3840, 2160)

@@ -122,7 +122,7 @@ def main():
 
     if 5 in want:  # depth-20 fractal, 3840x2160, 4 secondary rays per hit pixel
         t0 = time.time()
-        words = pkg.scenes.fractal(seed=1, max_depth=20, cam=(-0.9999, -0.9999, -0.9999), lod_c=3000.0, min_depth=4,
+        words = pkg.scenes.fractal(seed=0, max_depth=20, cam=(-0.9999, -0.9999, -0.9999), lod_c=3000.0, min_depth=4,
                                    max_words=120_000_000)
         print(f"config 5 scene: {words.size} words, depth {pkg.scenes.max_depth(words)}, built in {time.time() - t0:.1f}s", flush=True)
         W, H = 3840, 2160

@@ -41,7 +41,7 @@ def main():
     if a.deep:
         gpu.set_option(pkg.gpu.OPT_TREE_DEPTH, 20)
         scenes = {
-            "fractal20": pkg.scenes.fractal(seed=1, max_depth=20, cam=(-0.9999, -0.9999, -0.9999), lod_c=1200.0, min_depth=4, max_words=30_000_000),
+            "fractal20": pkg.scenes.fractal(seed=0, max_depth=20, cam=(-0.9999, -0.9999, -0.9999), lod_c=1200.0, min_depth=4, max_words=30_000_000),
             "terrain19": pkg.scenes.terrain(seed=2, max_depth=19, cam=pkg.scenes.terrain_camera(2, 19)[0], lod_c=250.0, max_words=30_000_000),
         }
         for name, words in scenes.items():
