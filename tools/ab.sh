@@ -5,5 +5,5 @@ for lib in "$@"; do
   SVO_HIP_LIB=$PWD/$lib python tools/perf_probe.py --lod 1500 --variants 1 --refill 16 --schedule 2 --reps 40 ${AB_ARGS:-} 2>/dev/null | grep '^{' | python3 -c "
 import sys,json
 for l in sys.stdin:
-    d=json.loads(l); print('$lib', d.get('pairs'), d['ms_med'], d['ms_min'], d['mrays_s'], d['sig'])"
+    d=json.loads(l); print('$lib', d['variant'], d['ms_med'], d['ms_min'], d['mrays_s'], d['sig'])"
 done; done

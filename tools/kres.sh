@@ -1,6 +1,6 @@
 #!/bin/bash
 # register / scratch / occupancy of every trace_stack_kernel instantiation (compiler view), one line each
-# template arguments: BLOCK, NS, K, GE, DBG, CNT, SHD, PAIRS
+# template arguments: BLOCK, NS, K, GE, DBG, CNT, SHD, ET
 cd /tmp && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I/root/repo/include -c --cuda-device-only \
   -Rpass-analysis=kernel-resource-usage /root/repo/octree-tracer_amd/csrc/svo_kernels.hip -o /tmp/kres.o 2>&1 | python3 -c "
 import sys,re

@@ -30,7 +30,6 @@ def main():
     ap.add_argument("--prio", default="0")
     ap.add_argument("--schedule", default="8")
     ap.add_argument("--block", default="3")
-    ap.add_argument("--pairs", default="0")
     ap.add_argument("--cull", default="2")
     ap.add_argument("--claim-at", default="64")
     ap.add_argument("--tail", default="0")
@@ -70,7 +69,7 @@ def main():
 
     ref = None
     for tail, claim_at, cull, pairs, blockw, variant, refill, strip, dyn, grid, prio, sched in itertools.product(
-            [int(x) for x in a.tail.split(",")], [int(x) for x in a.claim_at.split(",")], [int(x) for x in a.cull.split(",")], [int(x) for x in a.pairs.split(",")], [int(x) for x in a.block.split(",")],
+            [int(x) for x in a.tail.split(",")], [int(x) for x in a.claim_at.split(",")], [int(x) for x in a.cull.split(",")], [0], [int(x) for x in a.block.split(",")],
             [int(x) for x in a.variants.split(",")], [int(x) for x in a.refill.split(",")],
             [int(x) for x in a.strip.split(",")], [int(x) for x in a.dynamic.split(",")],
             [int(x) for x in a.grid.split(",")], [int(x) for x in a.prio.split(",")],
@@ -85,7 +84,6 @@ def main():
         set_opt(pkg.gpu.OPT_PRIO_STEPS, prio)
         set_opt(pkg.gpu.OPT_SCHEDULE, sched)
         set_opt(pkg.gpu.OPT_BLOCK_SHAPE, blockw)
-        set_opt(pkg.gpu.OPT_PAIR_TABLE, pairs)
         set_opt(pkg.gpu.OPT_CULL, cull)
         if hasattr(pkg.gpu, "OPT_LATE_TAIL"):
             set_opt(pkg.gpu.OPT_LATE_TAIL, tail)
@@ -110,7 +108,7 @@ def main():
             ref = h.copy()
         same = bool(np.array_equal(ref, h)) if not a.motion else None
         med = float(np.median(ms))
-        print(json.dumps({"tail": tail, "claim_at": claim_at, "cull": cull, "pairs": pairs, "variant": variant, "refill": refill, "strip": strip, "dynamic": dyn, "grid": grid, "prio": prio, "schedule": sched, "block": blockw,
+        print(json.dumps({"tail": tail, "claim_at": claim_at, "cull": cull, "variant": variant, "refill": refill, "strip": strip, "dynamic": dyn, "grid": grid, "prio": prio, "schedule": sched, "block": blockw,
                           "ms_med": round(med, 4), "ms_min": round(min(ms), 4), "mrays_s": round(n / med / 1e3, 1),
                           "sig": sig, "same_as_first": same}), flush=True)
     steps = (ref[:, 2] & 0xFF)
