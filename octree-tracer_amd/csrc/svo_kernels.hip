@@ -442,8 +442,10 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
 
     // write the record of a finished ray (deferred to the next refill so that it runs for many lanes at once)
     auto flush_record = [&](bool may_continue) {
-        const bool too_deep = (st & ST_F_TOODEEP) != 0u, solid = (st & ST_F_SOLID) != 0u, inb = (st & ST_F_INB) != 0u;
+        // (the leaf word the ray ended on is still in the lane's register: an interior word = the walk gave up at level SMAX)
+        const bool too_deep = leaf_w < (kVoxelOffset << 4), solid = (leaf_w >> 4) != kVoxelOffset, inb = (st & ST_F_INB) != 0u;
         const bool stop_here = too_deep || solid;
+        if (too_deep) atomicOr(a.status, 1u);  // reported by svo_sync
         const uint32_t L = (st >> ST_L_SHIFT) & 31u, nm = (st >> ST_M_SHIFT) & 7u;
         uint32_t c0n = (Dr0 > 0.0f) ? 2u : 1u, c1n = (Dr1 > 0.0f) ? 2u : 1u, c2n = (Dr2 > 0.0f) ? 2u : 1u;
         uint32_t ncode = ((nm & 1u) ? c0n : 0u) | ((nm & 2u) ? (c1n << 2) : 0u) | ((nm & 4u) ? (c2n << 4) : 0u);
@@ -916,20 +918,20 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                              (__builtin_fminf(__builtin_fminf(G0, G1), G2) >= -kScale);
             const bool stop_here = too_deep || solid;         // finish before stepping
             const uint32_t mbits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u);
-            // One branch for the common case -- an empty leaf, the step stays inside the cube and below the step cap (the
-            // count after this step exceeds 100 iff it is 100 now) -- and one for everything that ends the ray.
-            if (stop_here || !inb || (st & 0xFFu) >= 100u) {
-                if (!stop_here) {
-                    // the step is taken (its normal, distance and -- if it stays inside -- count are what the record shows)
-                    tcur = tnew;
-                    st = ((st & ~(ST_M_MASK | ST_ENTRY)) | (mbits << ST_M_SHIFT)) + (inb ? 1u : 0u);
-                }
-                if (too_deep) atomicOr(a.status, 1u);
-                st = (st & ~(ST_ACTIVE | ST_DESC)) | ST_PENDING | (too_deep ? ST_F_TOODEEP : 0u) |
-                     (solid ? ST_F_SOLID : 0u) | (inb ? ST_F_INB : 0u);
-            } else {
-                tcur = tnew;
-                st = ((st & ~(ST_M_MASK | ST_ENTRY)) | (mbits << ST_M_SHIFT)) + 1u;
+            // A ray ends here when its leaf is solid (or the walk gave up), when the step leaves the cube, or when the count after
+            // this step exceeds 100 (iff it is 100 now).  Some lane of a wave ends its ray in nine rounds of ten, so nothing of
+            // that sits in a branch of its own (round 3: the branch ran ~25 instructions for two lanes): the state of a ray that
+            // goes on and of one that ends differ by selects, and what the record needs beyond that -- solid / gave up -- is
+            // read off the leaf word when the record is written (flush_record).
+            const bool end = stop_here || !inb || (st & 0xFFu) >= 100u;
+            // the step is taken unless the ray stops in this leaf (its normal, distance and -- if it stays inside -- count are
+            // what the record shows)
+            tcur = stop_here ? tcur : tnew;
+            const uint32_t st_step = ((st & ~(ST_M_MASK | ST_ENTRY)) | (mbits << ST_M_SHIFT)) + (inb ? 1u : 0u);
+            st = stop_here ? st : st_step;
+            const uint32_t st_end = (st & ~(ST_ACTIVE | ST_DESC)) | ST_PENDING | (inb ? ST_F_INB : 0u);
+            st = end ? st_end : st;
+            if (!end) {
                 // new path codes: the position is inside the cube, so no clamping of G
                 int32_t jx, jy, jz;
                 if (GE) {
@@ -950,10 +952,11 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                 }
                 const uint32_t diff = (uint32_t)((ix ^ jx) | (iy ^ jy) | (iz ^ jz));
                 // levels shared by the old and new path: clz over the 24-bit codes (diff == 0: all 24)
-                const uint32_t c = (uint32_t)__clz((int)((diff << 8) | 0x80u));
+                // (diff == 0: all 24); + 1 = the first level that differs, folded into the shift
+                const uint32_t c1 = (uint32_t)__clz((int)((diff << 7) | 0x40u));
                 ix = jx; iy = jy; iz = jz;
                 st |= ST_DESC;
-                const uint32_t r = min(min(c + 1u, L), (uint32_t)SMAX);
+                const uint32_t r = min(c1, L);  // (L <= SMAX: the walk stops there)
                 if (CNT) {  // levels r and below belong to a new path
                     satm &= (1u << r) - 1u;
                 }
