@@ -444,15 +444,17 @@ def main():
                 if tj.get("workload") == a.workload and world == 1:
                     traffic = tj.get("hbm_bytes_per_launch")
                     valu = tj.get("valu_wave_instructions_per_launch")
-            # `bound` names the contractual ceiling (BASELINE.json: fraction of the HBM-read roofline on ALGORITHMIC bytes); the
-            # measured limiter is vector-instruction issue plus dependent-load latency: memory-side traffic is a fraction of
-            # the algorithmic bytes (L2 absorbs the shared ancestors), see roofline_valu and DESIGN.md 6
+            # `bound` names the contractual ceiling (BASELINE.json: fraction of the HBM-read roofline on ALGORITHMIC bytes); what
+            # the frame time actually follows is a balance of instruction issue and dependent-load latency: memory-side traffic is
+            # a fraction of the algorithmic bytes (L2 absorbs the shared ancestors), see roofline_valu and DESIGN.md 4.8 / 6
             result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                   "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (not this run)",
                                   "achieved_algorithmic_gbs": round(achieved, 2),
                                   "measured_hbm_gbs": round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 2) if traffic else None,
-                                  "measured_limiter": "vector-instruction issue + dependent-load latency (not HBM bandwidth)",
+                                  "measured_limiter": "no single resource: instruction issue and dependent-load latency in balance (same-box A/Bs, "
+                                                      "profiles/r03_sensitivity_ab.log: +10 % vector instructions -> +3..4 % time, twice the loads -> +5 %, "
+                                                      "a seventh wave per SIMD -> +3 %); not HBM bandwidth",
                                   "kernel": "trace_stack_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4),
                                   "algo_bytes_per_ray": round(bytes_per_ray, 3), "rays_per_launch": rays_per_launch}
             if valu:
