@@ -248,12 +248,12 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
             size_t want = n_strips < 4096 ? 4096 : n_strips;
             HIP_TRY(ctx, hipMalloc((void **)&sc.cost, want + 32 + svo::kOrderHistWords * sizeof(uint32_t)));
             HIP_TRY(ctx, hipMalloc((void **)&sc.cls_now, want + 32 + svo::kOrderHistWords * sizeof(uint32_t)));
-            HIP_TRY(ctx, hipMalloc((void **)&sc.order, (want + 8 * 24 + 8) * sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMalloc((void **)&sc.order, (want + 8 * (svo::kCostClasses + 8) + 8) * sizeof(uint32_t)));
             sc.cap = want;
         }
         // costs and order are only meaningful for the same work layout (same pixels behind every strip)
         if (sc.valid && memcmp(&sc.key, &wd, sizeof(wd)) != 0) sc.valid = false;
-        a.order_cap = (n_strips + 7u) / 8u + 16u;  // a list holds ceil(n_class / 8) strips of each of the 16 classes
+        a.order_cap = (n_strips + 7u) / 8u + svo::kCostClasses;  // a list holds ceil(n_class / 8) strips of each of the cost classes
         if (filtered) {
             // slots without a ray (secondary rays of pixels that hit nothing): this frame's lists leave out the strips
             // that consist of nothing else, ordered by the costs of an earlier frame when there are any
@@ -321,7 +321,7 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         // a camera in motion: strips near the long ones of this frame are not scheduled as cheap (strip_danger_kernel)
         const bool floor_now = rebuild && !filtered && moving && ctx->motion_floor != 0u && wd.mode == 0 && wd.n_rects == 1u;
         // (a launch with a skip mask builds its lists before the trace, every frame: here only the costs are measured)
-        HIP_TRY(ctx, svo::launch_post(a, li, rebuild ? sc.cost : nullptr, sc.order, n_strips, (n_strips + 7u) / 8u + 16u,
+        HIP_TRY(ctx, svo::launch_post(a, li, rebuild ? sc.cost : nullptr, sc.order, n_strips, (n_strips + 7u) / 8u + svo::kCostClasses,
                                       rebuild && !filtered, ctx->stream, floor_now ? sc.cls_now : nullptr, ctx->motion_floor));
         if (rebuild && !filtered) sc.floored = floor_now;
         sc.prev_uniforms = ctx->uniforms;

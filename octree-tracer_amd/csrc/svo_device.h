@@ -86,7 +86,11 @@ hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t
 int stack_max_depth(bool deep);
 // after a STACK trace: deferred rays, per-strip costs (cost != nullptr) and the next schedule; re-arms the counters
 constexpr uint32_t kMaxScheduledStrips = 1u << 20;  // (2^26 items / 64)
-constexpr uint32_t kOrderHistWords = 64 * 16;      // chunk histograms of the schedule builder, stored behind the class bytes
+// cost class of a strip = (largest step count among its rays) >> kCostShift: 4 steps per class -- with 8 the cheapest two classes of the
+// benchmark view hold 3 439 of 32 400 strips, fewer than the grid has waves, so every wave's last strip came from the 16..23-step
+// class in screen order; the finer classes end the lists with the strips that really are the shortest
+constexpr uint32_t kCostShift = 2, kCostClasses = 32;
+constexpr uint32_t kOrderHistWords = 64 * kCostClasses;  // chunk histograms of the schedule builder, stored behind the class bytes
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
                        uint32_t cap, bool build_schedule, hipStream_t stream, uint8_t *moved = nullptr, uint32_t motion_floor = 0);
 

@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(256) void post_kernel(TraceArgs a, uint32_t *claim_
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, o));
-            if (lane == 0) cost[s] = (uint8_t)min(steps >> 3, 15u);  // cost class
+            if (lane == 0) cost[s] = (uint8_t)min(steps >> kCostShift, kCostClasses - 1u);  // cost class
         }
     }
 }
@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256) void post_kernel(TraceArgs a, uint32_t *claim_
 // Output: sched[0..7] = entries per list, then 8 lists of `cap` strip numbers each.
 // Two small launches over kOrderBlocks workgroups, each owning a contiguous chunk of strips: class histogram
 // per chunk, then a stable counting sort (ballot + mbcnt ranks inside a wave, prefix over waves and chunks).
-constexpr uint32_t kOrderBlocks = 64, kOrderThreads = 256, kOrderBins = 16, kOrderLists = 8;
+constexpr uint32_t kOrderBlocks = 64, kOrderThreads = 256, kOrderBins = kCostClasses, kOrderLists = 8;
 
 __device__ __forceinline__ uint32_t order_chunk(uint32_t n_strips) {
     return (((n_strips + kOrderBlocks - 1) / kOrderBlocks) + 63u) & ~63u;  // whole 64-strip groups per workgroup
@@ -1649,7 +1649,7 @@ __global__ __launch_bounds__(256) void strip_danger_kernel(const uint8_t *in, ui
                 const int y = by + dy, x = bx + dx;
                 if (y < 0 || y >= rows || x < 0 || x >= (int)bpr) continue;
                 const uint32_t t = (uint32_t)y * bpr + (uint32_t)x;
-                if (t < n_strips && in[t] >= 8u) near++;
+                if (t < n_strips && in[t] >= (64u >> kCostShift)) near++;  // a ray of 64 steps or more
             }
         if (near >= min_count) c = floor_class;
     }
@@ -1669,7 +1669,7 @@ hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cos
         const uint8_t *cls = cost;
         if (moved && motion_floor) {  // (pixel frames of one rectangle: the ABI passes `moved` only then)
             hipLaunchKernelGGL(strip_danger_kernel, dim3((n_strips + 255u) / 256u), dim3(256), 0, stream, (const uint8_t *)cost, moved, n_strips,
-                               args.work.bpr, (int)((motion_floor >> 8) & 15u), (motion_floor >> 12) & 255u, motion_floor & 15u);
+                               args.work.bpr, (int)((motion_floor >> 8) & 15u), (motion_floor >> 12) & 255u, ((motion_floor & 15u) << 3) >> kCostShift);  // (the option counts the floor in units of 8 steps)
             cls = moved;
         }
         // the chunk histograms live behind the class bytes (the ABI allocates kOrderHistWords extra words)
