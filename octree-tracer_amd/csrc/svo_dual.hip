@@ -1,4 +1,9 @@
-// svo_dual.hip -- the STACK traversal with TWO rays per lane, software-pipelined, for static trees.
+// svo_dual.hip -- round 3's experiment: the STACK traversal with TWO rays per lane, software-pipelined, over a
+// child-mask table, for static trees.  It does what it was built for -- waves wait at s_waitcnt half as long, a DDA step costs 1.05
+// loads instead of 1.8 -- and is 2.5 x SLOWER than trace_stack_kernel on the benchmark frame: 1.75 x the instructions per frame, and a
+// ray advances once per loop iteration of two turns, which stretches the serial chain of the 101-step rays past the whole frame.  It
+// stays selectable (SVO_VARIANT_DUAL) under the parity tests and campaigns so that the measurement can be repeated; the default
+// kernel does not use this file's table either (SVO_VARIANT_ETAB does: svo_kernels.hip, template flag ET).
 //
 // What bounds trace_stack_kernel (svo_kernels.hip) is one dependent load per octree level with nothing else for the
 // wave to do: every lane waits for the deepest lane's walk, 550 cycles per level.  Two changes here,
