@@ -75,6 +75,10 @@ def main():
                          "1 -> 8 GPU target of BASELINE.json refers to (the 1080p frame of the same scene is then under config.also)")
     ap.add_argument("--tile-w", type=int, default=64)
     ap.add_argument("--tile-h", type=int, default=8)
+    ap.add_argument("--preroll", type=int, default=60,
+                    help="untimed frames traced once before the W warm-up steps of the headline measurement: the first frames after "
+                         "start-up run 4 - 5 %% slower than the steady state the chip reaches after ~40 frames (12 ms) of this kernel "
+                         "(profiles/r03_ramp_probe.log); reported as config.preroll_frames.  0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold-frame / moving-camera / other-workload measurements")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -253,12 +257,18 @@ def main():
                                               words=1 if colour else 4)
         return pipe.step, pipe.drain
 
+    preroll = [max(0, a.preroll)]
+
     def measure(W, H, steps, warmup, wire, serial_one_gpu=False):
         """K timed frames: (elapsed s [max over ranks], kernel ms of the K launches, last frame)"""
         step, drain = frame_loop(W, H, wire, serial_one_gpu)
         bar = torch.cuda.synchronize if serial_one_gpu else barrier  # (the one-GPU reference runs on rank 0 alone: no collective)
         for g, _, _ in lanes:
             g.set_option(pkg.gpu.OPT_TIMING, max(steps, 1))
+        if preroll[0] > 0:  # once per process: the chip's clocks settle over the first ~40 frames (same count on every rank)
+            for _ in range(preroll[0]):
+                step()
+            preroll[0] = 0
         for _ in range(warmup):
             step()
         if drain:
@@ -381,6 +391,8 @@ def main():
             "config": {"workload": a.workload, "width": W, "height": H, "octree_max_depth": wl["max_depth"],
                        "node_words": int(words.size), "node_bytes": int(words.size) * 4, "rays_per_step": n_rays,
                        "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight,
+                       "preroll_frames": max(0, a.preroll),
+                       "preroll": "untimed frames before the warm-up steps, so that the K timed steps run at the chip's steady-state clocks",
                        "step_semantics": ("frames are serial: ms_per_step is one frame's latency and roofline.kernel_avg_ms one un-overlapped launch"
                                           if a.frames_in_flight == 1 else
                                           f"{a.frames_in_flight} frames in flight on separate HIP streams: ms_per_step is the interval between completed "
