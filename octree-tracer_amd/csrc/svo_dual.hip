@@ -131,14 +131,13 @@ __global__ __launch_bounds__(BLOCK, 4) void trace_dual_kernel(TraceArgs a, uint3
     constexpr uint32_t kNoLoad = 0x7FFFFFF0u;  // byte offset past any buffer: the load returns 0 without touching memory
     extern __shared__ uint32_t lds[];
     uint32_t *tbl = lds;                             // TBL entries
-    uint32_t *stk = lds + TBL;                       // [2][NS][BLOCK]: row l - SBASE = E entry of the ray's child group of level l
-    uint32_t *pool_all = stk + 2 * NS * BLOCK;       // [BLOCK / 64][kPoolWords][64]
+    // lds + TBL: the two ancestor stacks [2][NS][BLOCK], row l - SBASE = E entry of the ray's child group of level l
+    uint32_t *pool_all = lds + TBL + 2 * NS * BLOCK;  // [BLOCK / 64][kPoolWords][64]
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     uint32_t *pool = pool_all + (tid >> 6) * (kPoolWords * 64);
     const uint32_t col_a = (uint32_t)TBL + tid, col_b = (uint32_t)TBL + (uint32_t)(NS * BLOCK) + tid;  // row 0 of the lane's two stack columns (index into lds)
-    (void)stk;
     const rsrc_t re = make_rsrc(a.etab, a.n_words);
 
     for (uint32_t i = tid; i < (uint32_t)TBL; i += BLOCK) tbl[i] = a.top_table[i];

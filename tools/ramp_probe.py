@@ -1,8 +1,10 @@
-import sys, json, numpy as np
-sys.path.insert(0,'/root/repo')
+"""Developer probe: kernel time of each of the first 120 frames of the benchmark workload after start-up (the chip's clocks and
+caches settle over the first ~40): why bench.py traces untimed pre-roll frames.  usage: python tools/ramp_probe.py"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as e
 pkg = e.load_package()
-import torch
 cam, look = pkg.scenes.terrain_camera(0, 16)
 words = pkg.scenes.terrain(seed=0, max_depth=16, cam=cam, lod_c=1500.0, max_words=125_000_000)
 gpu = pkg.Gpu(0)
