@@ -75,9 +75,9 @@ def main():
                          "1 -> 8 GPU target of BASELINE.json refers to (the 1080p frame of the same scene is then under config.also)")
     ap.add_argument("--tile-w", type=int, default=64)
     ap.add_argument("--tile-h", type=int, default=8)
-    ap.add_argument("--preroll", type=int, default=60,
+    ap.add_argument("--preroll", type=int, default=120,
                     help="untimed frames traced once before the W warm-up steps of the headline measurement: the first frames after "
-                         "start-up run 4 - 5 %% slower than the steady state the chip reaches after ~40 frames (12 ms) of this kernel "
+                         "start-up run 4 - 5 %% slower than the steady state the chip reaches after 40 - 80 frames (12 - 25 ms) of this kernel "
                          "(profiles/r03_ramp_probe.log); reported as config.preroll_frames.  0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold-frame / moving-camera / other-workload measurements")
