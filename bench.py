@@ -257,7 +257,7 @@ def main():
                                               words=1 if colour else 4)
         return pipe.step, pipe.drain
 
-    preroll = [max(0, a.preroll)]
+    preroll = [0 if (pipelined and a.backend == "gloo") else max(0, a.preroll)]  # (gloo: validation mode, not a performance configuration)
 
     def measure(W, H, steps, warmup, wire, serial_one_gpu=False):
         """K timed frames: (elapsed s [max over ranks], kernel ms of the K launches, last frame)"""
@@ -391,7 +391,7 @@ def main():
             "config": {"workload": a.workload, "width": W, "height": H, "octree_max_depth": wl["max_depth"],
                        "node_words": int(words.size), "node_bytes": int(words.size) * 4, "rays_per_step": n_rays,
                        "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight,
-                       "preroll_frames": max(0, a.preroll),
+                       "preroll_frames": 0 if (pipelined and a.backend == "gloo") else max(0, a.preroll),
                        "preroll": "untimed frames before the warm-up steps, so that the K timed steps run at the chip's steady-state clocks",
                        "step_semantics": ("frames are serial: ms_per_step is one frame's latency and roofline.kernel_avg_ms one un-overlapped launch"
                                           if a.frames_in_flight == 1 else
