@@ -49,6 +49,13 @@ def cell_word(k):
     return 8 * (63 + k // 2) + 6 + k % 2
 
 
+def b_tree():
+    """one level, child 7 solid"""
+    b = np.full(8, EMPTY, dtype=np.uint32)
+    b[7] = solid(0xFF0000)
+    return b
+
+
 def rec(value, t, steps, depth, hit, normal_bits):
     return dict(value=value, t=np.float32(t), steps=steps, depth=depth, hit=hit, normal_bits=normal_bits)
 
@@ -77,6 +84,27 @@ def cases():
     a2[15] = solid(0x00FF00)
     out.append(("two levels, hit at depth 2", a2, F_PAUSE_ADAPTIVE, np.array([[0.5, 0.5, -3, 0, 0, 1]], dtype=np.float32),
                 [rec(15, 2.5, 1, 2, 1, 2 << 4)]))
+    # ---- A'': going down (-z) through the column with root child 7 EMPTY: pos (0.5, 0.5, 3), dir (0, 0, -1), dist 2, entry z = 1.
+    #   Walk 1: child 7 (depth 1, centre z 0.5, size 1): t_z = (0.5 - 1 + (-1) * 0.5) / (-1) = 1; the normal is +z, so
+    #     voxel_pos z = 1 - 1 - 2e-6 = -2e-6.  Walk 2: child 6 -> group 8, z > -0.5 -> word 15 (centre z -0.25, size 0.5):
+    #     t_z = (-0.25 - 1 - 0.25) / (-1) = 1.5; voxel_pos z = -0.5 - 2e-6.  Walk 3: z > -0.5 no -> word 14 (centre z -0.75):
+    #     t_z = (-0.75 - 1 - 0.25) / (-1) = 2; voxel_pos z = -1 - 2e-6: left the cube after two counted steps: t = 2 + 2, depth 2.
+    a3 = a.copy()
+    a3[7] = EMPTY
+    out.append(("two levels, downwards, leaves through the bottom", a3, F_PAUSE_ADAPTIVE, np.array([[0.5, 0.5, 3, 0, 0, -1]], dtype=np.float32),
+                [rec(MISS_LEFT, 4.0, 2, 2, 0, 0)]))
+    # ---- F: the cube's faces and the box test (shader.wgsl:66-80, 177-180, 197-205), one level, child 7 solid.
+    #   Ray 1: pos (1.5, 0.25, 0.25), dir (-1, 0, 0): x slab [(1 - 1.5) / -1, (-1 - 1.5) / -1] = [0.5, 2.5], y / z slabs [-inf, inf] ->
+    #     dist 0.5; entry (1.5 - 0.5, 0.25 + 1e-6 * 0.5, same) = (1, 0.2500005, 0.2500005): every component > 0 -> child 7, solid at
+    #     once: steps 0, t = 0.5, normal = trunc((1, 0.25, 0.25) * 1.000001) = (1, 0, 0).
+    #   Ray 2: the same ray started ON the face: pos (1, 0.25, 0.25).  in_bounds wants x < 1, so the box test runs: x slab
+    #     [(1 - 1) / -1, (-1 - 1) / -1] = [-0, 2] -> v7 = -0, v8 = 2: ray_box_dist returns -0.0, which octree_ray reads as "0 = no
+    #     intersection" (dist == 0.0): the ray never enters -- the all-zero record.  (A quirk of the reference, kept.)
+    #   Ray 3: parallel to z beside the cube: pos (2, 0.5, -3), dir (0, 0, 1): x slab [(-1 - 2) / 0, (1 - 2) / 0] = [-inf, -inf],
+    #     v8 = -inf < 0 -> 0: never enters.
+    out.append(("faces and the box test", b_tree(), F_PAUSE_ADAPTIVE,
+                np.array([[1.5, 0.25, 0.25, -1, 0, 0], [1.0, 0.25, 0.25, -1, 0, 0], [2, 0.5, -3, 0, 0, 1]], dtype=np.float32),
+                [rec(7, 0.5, 0, 1, 1, 1), rec(0, 0.0, 0, 0, 0, 0), rec(0, 0.0, 0, 0, 0, 0)]))
     # ---- B: three-axis tie.  One level, child 7 solid.  pos (-3, -3, -3), dir (1, 1, 1) (not normalised: octree_ray takes it as
     #   it is).  Every slab is [2, 4] -> dist 2, entry (-1, -1, -1): child 0, centre -0.5, size 1, empty.
     #   t_x = t_y = t_z = (-0.5 + 1 + 0.5) / 1 = 1: all three attain the minimum -> normal (-1, -1, -1);
