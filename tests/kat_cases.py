@@ -160,3 +160,35 @@ def check(hits, expected, what):
         got = dict(value=int(h["value"]), t=np.float32(h["t"]), steps=int(h["info"] & 0xFF), depth=int((h["info"] >> 8) & 0xFF),
                    hit=int((h["info"] >> 16) & 1), normal_bits=int(h["normal_bits"]))
         assert got == e, f"{what}, ray {i}: got {got}, derived by hand {e}"
+
+
+def one_ray_camera_inverse(pos, direction):
+    """camera_inverse (column-major) of a 1 x 1 frame whose only ray is exactly (pos, direction): the pixel centre is clip (0, 0)
+    (shader.wgsl:253-259: (0.5 / 1 * 2 - 1) * (1, -1)), so origin = (Cinv * (0, 0, 0, 1)).xyz / w = column 3 and
+    direction = normalize((Cinv * (0, 0, 1, 1)).xyz / w - origin) = normalize(column 2) (shader.wgsl:54-59).  `direction` must be of
+    length exactly 1 and pos + direction exactly representable for the ray to be exact."""
+    m = np.zeros(16, dtype=np.float32)
+    m[0] = 1.0                                  # column 0 = (1, 0, 0, 0)
+    m[5] = 1.0                                  # column 1 = (0, 1, 0, 0)
+    m[8:11] = direction                         # column 2 = (d, 0)
+    m[12:15] = pos                              # column 3 = (p, 1)
+    m[15] = 1.0
+    return m
+
+
+def counter_case():
+    """Hit counters (shader.wgsl:157-161) derived by hand.  find_voxel bumps EVERY word it reads -- interior words and the leaf
+    alike, before the leaf test -- once per call, while `primary && counter < 15 && !pause_adaptive`.  Tree A of cases() (two
+    levels), the one ray (0.5, 0.5, -3) -> (0, 0, 1), counters live, no shadow ray: walk 1 reads words 6 and 14, walk 2 words 6 and
+    15, walk 3 word 7 (the hit).  After n frames: word 6 carries min(15, 2n), words 14, 15 and 7 min(15, n); nothing else changes.
+    Returns (words, camera_inverse, record of the ray, function n -> expected words)."""
+    name, words, flags, rays, expected = cases()[0]
+    cinv = one_ray_camera_inverse(rays[0, :3], rays[0, 3:])
+
+    def after(n):
+        w = words.copy()
+        w[6] += min(15, 2 * n)
+        for i in (14, 15, 7):
+            w[i] += min(15, n)
+        return w
+    return words, cinv, expected[0], after

@@ -70,6 +70,20 @@ def test_hand_derived_rays(O):
         K.check(O.trace_rays(words, rays, flags=flags), expected, name)
 
 
+def test_hand_derived_hit_counters(O):
+    """tests/kat_cases.py counter_case: a 1 x 1 frame whose camera matrix makes its only ray a hand-derived one; the counters the
+    frame leaves in the node words are worked out on paper (every word a walk reads, leaf included, +1 per walk, up to 15)."""
+    import kat_cases as K
+    words, cinv, record, after = K.counter_case()
+    u = O.make_uniforms(width=1, height=1, flags=0)  # counters live, no shadow ray
+    u.camera_inverse[:] = cinv.tolist()
+    K.check(O.trace_frame(words, u).reshape(-1), [record], "the 1 x 1 frame's ray")
+    w = words
+    for n in range(1, 10):  # word 6 saturates in frame 8
+        w = O.count_frame(w, u)
+        assert np.array_equal(w, after(n)), f"counters after {n} frames"
+
+
 def test_single_level_rays(O):
     """KATs 4-6: tree with only child 7 solid."""
     words = np.array([0x80000000] * 7 + [0x8FF00000], dtype=np.uint32)

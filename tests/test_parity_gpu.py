@@ -159,6 +159,24 @@ def test_hand_derived_known_answers(pkg, gpu, O, variant):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
+def test_hand_derived_hit_counters(pkg, gpu, O, variant):
+    """tests/kat_cases.py counter_case on the device: the node words a 1 x 1 frame of one hand-derived ray leaves behind, frame after
+    frame up to saturation, against the counters worked out on paper (shader.wgsl:157-161)."""
+    import kat_cases as K
+    words, cinv, record, after = K.counter_case()
+    gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+    u = O.make_uniforms(width=1, height=1, flags=0)  # counters live, no shadow ray
+    u.camera_inverse[:] = cinv.tolist()
+    render = pkg.Render(gpu, (1, 1), words, capacity=64)
+    set_uniforms_from_oracle(render, u)
+    for n in range(1, 10):
+        hits = pkg.render.hits_to_numpy(render.render())
+        gpu.sync()
+        K.check(hits, [record], f"the 1 x 1 frame's ray, frame {n}")
+        assert np.array_equal(render.read_nodes(words.size), after(n)), f"counters after {n} frames (variant {variant})"
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_step_limit_and_malformed(pkg, gpu, O, variant):
     """>100 steps sentinel (shader.wgsl:242-244) and a malformed array (zero words = a pointer cycle):
     the kernel must terminate and report the sentinel like the oracle."""
