@@ -192,3 +192,21 @@ def counter_case():
             w[i] += min(15, n)
         return w
     return words, cinv, expected[0], after
+
+
+def shading_cases():
+    """fs_main (shader.wgsl:261-304) by hand, on 1 x 1 frames of tree A (cases()[0]).
+    Hit pixel: the ray (0.5, 0.5, -3) -> (0, 0, 1) ends on word 7, colour (255, 0, 0), normal (0, 0, -1).  sun_dir (-1.7, -1, 0.8),
+    |sun| = sqrt(2.89 + 1 + 0.64) = 2.12838; diffuse = max(dot(n, -sun / |sun|), 0) = 0.8 / 2.12838 = 0.37587; the shadow ray (from the hit
+    point, 5e-7 below z = 0, towards (0.799, 0.470, -0.376)) crosses only empty cells and leaves through the face x = 1 at t = 0.63: lit.
+    colour = (0.3 + 0.37587) * (1, 0, 0) = 0.67587; 0.67587 ^ 2.2 = 0.42238 -> 108.2 -> 108; alpha 0.5 -> 128.
+    Miss pixel: the same origin looking away (0, 0, -1) never enters the cube: 0.2 grey, 0.2 ^ 2.2 = 0.02899 -> 7.9 -> 7.
+    Returns [(name, words, flags, camera_inverse, sun_dir, expected RGBA8)]; pow() may move a channel by one code value."""
+    name, words, flags, rays, expected = cases()[0]
+    sun = (-1.7, -1.0, 0.8, 0.0)
+    F_SHADOWS = 8
+    hit = one_ray_camera_inverse(rays[0, :3], rays[0, 3:])
+    away = one_ray_camera_inverse(rays[0, :3], np.array([0, 0, -1], dtype=np.float32))
+    return [("lit hit, no shadow ray", words, F_PAUSE_ADAPTIVE, hit, sun, (108, 0, 0, 128)),
+            ("lit hit, shadow ray finds nothing", words, F_PAUSE_ADAPTIVE | F_SHADOWS, hit, sun, (108, 0, 0, 128)),
+            ("miss", words, F_PAUSE_ADAPTIVE | F_SHADOWS, away, sun, (7, 7, 7, 128))]

@@ -84,6 +84,16 @@ def test_hand_derived_hit_counters(O):
         assert np.array_equal(w, after(n)), f"counters after {n} frames"
 
 
+def test_hand_derived_shading(O):
+    """tests/kat_cases.py shading_cases: fs_main's colour of a hit pixel and of a miss pixel, worked out on paper."""
+    import kat_cases as K
+    for name, words, flags, cinv, sun, rgba in K.shading_cases():
+        u = O.make_uniforms(width=1, height=1, flags=flags, sun_dir=sun)
+        u.camera_inverse[:] = cinv.tolist()
+        got = np.floor(np.clip(O.shade_frame(words, u).reshape(4), 0, 1) * 255.0 + 0.5).astype(np.int32)
+        assert np.abs(got - np.array(rgba)).max() <= 1 and got[3] == rgba[3], f"{name}: {got.tolist()} against {rgba}"
+
+
 def test_single_level_rays(O):
     """KATs 4-6: tree with only child 7 solid."""
     words = np.array([0x80000000] * 7 + [0x8FF00000], dtype=np.uint32)

@@ -177,6 +177,27 @@ def test_hand_derived_hit_counters(pkg, gpu, O, variant):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("fused_shadows", [0, 1])
+def test_hand_derived_shading(pkg, gpu, O, variant, fused_shadows):
+    """tests/kat_cases.py shading_cases on the device: the RGBA8 pixel of fs_main for a lit hit (with and without its shadow ray)
+    and for a miss, against the colours worked out on paper (one code value of slack for pow)."""
+    import kat_cases as K
+    gpu.set_option(pkg.gpu.OPT_VARIANT, variant)
+    gpu.set_option(pkg.gpu.OPT_FUSED_SHADOWS, fused_shadows)
+    try:
+        for name, words, flags, cinv, sun, rgba in K.shading_cases():
+            u = O.make_uniforms(width=1, height=1, flags=flags, sun_dir=sun)
+            u.camera_inverse[:] = cinv.tolist()
+            render = pkg.Render(gpu, (1, 1), words, capacity=64)
+            set_uniforms_from_oracle(render, u)
+            hits, img = render.render_host(rgba=True)
+            got = img.reshape(4).astype(np.int32)
+            assert np.abs(got - np.array(rgba)).max() <= 1 and got[3] == rgba[3], f"{name} (variant {variant}): {got.tolist()} against {rgba}"
+    finally:
+        gpu.set_option(pkg.gpu.OPT_FUSED_SHADOWS, 2)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_step_limit_and_malformed(pkg, gpu, O, variant):
     """>100 steps sentinel (shader.wgsl:242-244) and a malformed array (zero words = a pointer cycle):
     the kernel must terminate and report the sentinel like the oracle."""
