@@ -74,6 +74,18 @@ def test_vox_errors(pkg, O, tmp_path):
     assert len(pkg.CpuOctree.load_file(q)) == 8 * 3  # one voxel at depth 3: the root group + 2 subdivisions
 
 
+def test_hand_made_rsvo_stream(pkg):
+    """The product's .rsvo reader on the stream assembled by hand in tests/test_oracle_kat.py (not a product of this repository's
+    writer): same expected trees as the oracle's reader."""
+    from test_oracle_kat import check_hand_made_rsvo, hand_made_rsvo
+
+    def load(depth):
+        t = pkg.CpuOctree.load_octree(hand_made_rsvo(), depth)
+        ptrs, rgb = t.raw()
+        return ptrs, rgb, t.to_octree_words()
+    check_hand_made_rsvo(load, pkg.CHUNK_OFFSET)
+
+
 def test_rsvo_round_trip(pkg, O):
     """.rsvo BFS child-mask stream (cpu_octree.rs:128-175): writer -> both loaders, and depth truncation."""
     size, xyzi, pal, n, _ = load_vox_fixture("small")

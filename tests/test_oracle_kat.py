@@ -94,6 +94,48 @@ def test_hand_derived_shading(O):
         assert np.abs(got - np.array(rgba)).max() <= 1 and got[3] == rgba[3], f"{name}: {got.tolist()} against {rgba}"
 
 
+def hand_made_rsvo():
+    """A .rsvo stream assembled by hand from the reader's rules (cpu_octree.rs:128-175): 16 header bytes (ignored), byte 16 =
+    top_level, from byte 20 top_level + 1 little-endian u32 node counts per level, then one child-mask byte per node in
+    breadth-first order, the root's first.  Here: top_level 2; counts 1, 2, 3; root mask 0b101 (children 0 and 2), their masks
+    0b10000000 (child 7) and 0b00000011 (children 0, 1), then three level-2 masks that a depth-2 load must not look at."""
+    import struct
+    return (b"hand-made header" + bytes([2, 0, 0, 0]) + struct.pack("<3I", 1, 2, 3) + bytes([0b101, 0b10000000, 0b00000011, 0xFF, 0x01, 0x80]))
+
+
+def check_hand_made_rsvo(load, CHUNK):
+    """Expected trees (CpuOctree::new / add_voxels, cpu_octree.rs:23-45: a set bit becomes a block reference CHUNK_OFFSET + (index % 8)
+    + 1 coloured (255, 0, 0), a clear bit CHUNK_OFFSET coloured black; load_octree turns a reference into a pointer to 8 new nodes
+    while masks of the first `octree_depth` levels are left).
+    depth 2: node 0 -> group 8, node 2 -> group 16; group 8 holds one reference (node 15 = CHUNK_OFFSET + 8), group 16 two (nodes 16,
+    17 = CHUNK_OFFSET + 1, + 2); they stay references (their masks belong to level 2).  depth 1: the root's own 8 nodes only."""
+    red = [255, 0, 0]
+    ptrs, rgb, words = load(2)
+    want = [CHUNK] * 24
+    want[0], want[2], want[15], want[16], want[17] = 8, 16, CHUNK + 8, CHUNK + 1, CHUNK + 2
+    assert ptrs.tolist() == want
+    assert [i for i in range(24) if rgb[i].tolist() == red] == [0, 2, 15, 16, 17] and not rgb[[1, 3, 8, 23]].any()
+    empty, solid = 0x80000000, 0x8FF00000
+    assert words.tolist() == [8 << 4, empty, 16 << 4] + [empty] * 12 + [solid, solid, solid] + [empty] * 6   # to_octree, :233-252
+    ptrs, rgb, words = load(1)
+    assert ptrs.tolist() == [CHUNK + 1, CHUNK, CHUNK + 3] + [CHUNK] * 5
+    assert words.tolist() == [solid, empty, solid] + [empty] * 5
+    try:
+        load(3)
+        raise AssertionError("a depth above the stream's top level must be refused")
+    except ValueError as e:
+        assert "greater than top level" in str(e)
+
+
+def test_hand_made_rsvo_stream(O):
+    """The .rsvo reader against a stream NOT produced by this repository's writer (no real .rsvo model is in the reference checkout)."""
+    def load(depth):
+        t = O.Tree.from_rsvo(hand_made_rsvo(), depth)
+        ptrs, rgb = t.raw()
+        return ptrs, rgb, t.to_octree()
+    check_hand_made_rsvo(load, O.CHUNK_OFFSET)
+
+
 def test_single_level_rays(O):
     """KATs 4-6: tree with only child 7 solid."""
     words = np.array([0x80000000] * 7 + [0x8FF00000], dtype=np.uint32)
