@@ -86,6 +86,12 @@ def test_hand_made_rsvo_stream(pkg):
     check_hand_made_rsvo(load, pkg.CHUNK_OFFSET)
 
 
+def test_hand_made_vox_file(pkg):
+    """The product's .vox reader on the file assembled by hand in tests/test_oracle_kat.py."""
+    from test_oracle_kat import check_hand_made_vox, hand_made_vox
+    check_hand_made_vox(pkg.CpuOctree.load_vox(hand_made_vox()).to_octree_words(), pkg.VOXEL_OFFSET)
+
+
 def test_rsvo_round_trip(pkg, O):
     """.rsvo BFS child-mask stream (cpu_octree.rs:128-175): writer -> both loaders, and depth truncation."""
     size, xyzi, pal, n, _ = load_vox_fixture("small")

@@ -136,6 +136,40 @@ def test_hand_made_rsvo_stream(O):
     check_hand_made_rsvo(load, O.CHUNK_OFFSET)
 
 
+def hand_made_vox():
+    """A MagicaVoxel file assembled by hand (format: 'VOX ' 150, MAIN { SIZE, XYZI, RGBA }): a 2 x 2 x 2 model with two voxels,
+    (x, y, z, colour index) = (0, 0, 0, 1) and (1, 0, 1, 2); RGBA entry k colours index k + 1: entry 0 = (10, 20, 30), entry 1 =
+    (200, 100, 50)."""
+    import struct
+
+    def chunk(cid, content, children=b""):
+        return cid + struct.pack("<II", len(content), len(children)) + content + children
+    size = chunk(b"SIZE", struct.pack("<III", 2, 2, 2))
+    xyzi = chunk(b"XYZI", struct.pack("<I", 2) + bytes([0, 0, 0, 1]) + bytes([1, 0, 1, 2]))
+    pal = bytearray(1024)
+    pal[0:4] = bytes([10, 20, 30, 255])
+    pal[4:8] = bytes([200, 100, 50, 255])
+    rgba = chunk(b"RGBA", bytes(pal))
+    return b"VOX " + struct.pack("<I", 150) + chunk(b"MAIN", b"", size + xyzi + rgba)
+
+
+def check_hand_made_vox(words, V):
+    """load_vox (cpu_octree.rs:177-210): depth = log2(2) = 1; pos = ((size - x - 1, z, y) / size) * 2 - 1:
+    voxel 1 -> (0, -1, -1): CpuOctree::find_voxel compares with >= (cpu_octree.rs:57-61): child 4 * 1 + 0 + 0 = 4, colour of index 1 =
+    RGBA entry 0; voxel 2 -> (-1, 0, -1): child 0 + 2 * 1 + 0 = 2, colour of index 2 = RGBA entry 1.  Voxel::to_value = r << 16 | g << 8 | b
+    on top of VOXEL_OFFSET (octree.rs:28-35)."""
+    want = [V << 4] * 8
+    want[4] = (V + (10 << 16 | 20 << 8 | 30)) << 4
+    want[2] = (V + (200 << 16 | 100 << 8 | 50)) << 4
+    assert words.tolist() == want
+
+
+def test_hand_made_vox_file(O):
+    """The .vox parser, the colour-index convention inferred for dot_vox 4.1 (voxel.i = file index - 1) and load_vox's axis swap,
+    on a file assembled by hand."""
+    check_hand_made_vox(O.Tree.from_vox(hand_made_vox()).to_octree(), O.VOXEL_OFFSET)
+
+
 def test_single_level_rays(O):
     """KATs 4-6: tree with only child 7 solid."""
     words = np.array([0x80000000] * 7 + [0x8FF00000], dtype=np.uint32)
