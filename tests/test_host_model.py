@@ -144,6 +144,31 @@ def test_mip_tree_matches_oracle(pkg, O):
     assert ca[i].tolist() == np.maximum(nz.mean(axis=0).astype(np.uint8), 1).tolist()
 
 
+def test_mip_colours_by_hand(pkg, O):
+    """World::generate_mip_tree (world.rs:234-336) on a tree small enough to do on paper.  Root child 0 is subdivided (put_in_voxel
+    at depth 2, cpu_octree.rs:100-111) and holds (10, 20, 30) and (20, 40, 61) among six black children; root child 5 is the leaf
+    (100, 0, 7).  A node's colour = the f32 mean of its non-black children, truncated to u8, each channel at least 1:
+    node 0 = ((10 + 20) / 2, (20 + 40) / 2, (30 + 61) / 2 = 45.5 -> 45).  Root child 3 is subdivided into eight black leaves: 0 / 0 = NaN ->
+    `as u8` 0 -> max(1): (1, 1, 1) -- which then counts as a non-black child of the root: top_mip = mean of (15, 30, 45), (1, 1, 1), (100, 0, 7)."""
+    V = pkg.Voxel
+    for make, put, mips, raw in (
+            (lambda: pkg.CpuOctree.new(0), lambda t, p, c, d: t.put_in_voxel(p, V(*c), d), lambda t: (lambda v: (v.r, v.g, v.b))(t.generate_mip_tree()), lambda t: t.raw()),
+            (lambda: O.Tree.new(0), lambda t, p, c, d: t.put_in_voxel(p, c, d), lambda t: tuple(t.generate_mips()), lambda t: t.raw())):
+        t = make()
+        put(t, (-0.75, -0.75, -0.75), (10, 20, 30), 2)   # root child 0 -> group 8, its child 0
+        put(t, (-0.75, -0.75, -0.25), (20, 40, 61), 2)   # its child 1 (z >= -0.5)
+        put(t, (0.5, -0.5, 0.5), (100, 0, 7), 1)         # root child 4 + 0 + 1 = 5
+        put(t, (-0.75, 0.75, 0.75), (0, 0, 0), 2)        # root child 3 subdivided into eight black leaves -> group 16
+        top = mips(t)
+        ptrs, rgb = raw(t)
+        assert ptrs[0] == 8 and ptrs[3] == 16 and len(ptrs) == 24
+        assert rgb[8].tolist() == [10, 20, 30] and rgb[9].tolist() == [20, 40, 61] and rgb[5].tolist() == [100, 0, 7]
+        assert rgb[0].tolist() == [15, 30, 45]
+        assert rgb[3].tolist() == [1, 1, 1]
+        # the root: children 0 (15, 30, 45), 3 (1, 1, 1), 5 (100, 0, 7): (116 / 3 = 38.67 -> 38, 31 / 3 = 10.33 -> 10, 53 / 3 = 17.67 -> 17)
+        assert top == (38, 10, 17)
+
+
 def test_octree_subdivide_unsubdivide(pkg):
     """octree.rs:51-110: free-list reuse, panics as exceptions, pos_offset KAT 2."""
     V = pkg.Voxel
