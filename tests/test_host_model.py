@@ -169,6 +169,23 @@ def test_mip_colours_by_hand(pkg, O):
         assert top == (38, 10, 17)
 
 
+def test_camera_matrices_by_hand(pkg, O):
+    """Render::update's matrices (render.rs:191-206, main.rs:139-162) for a pose that can be done on paper: eye (0, 0, -2) looking
+    along +z, 200 x 100 pixels, fov 90.  cgmath's look_at_rh: f = (0, 0, 1), s = normalize(f x up) = (-1, 0, 0), u = s x f = (0, 1, 0);
+    view columns (s.x, u.x, -f.x, 0), (s.y, u.y, -f.y, 0), (s.z, u.z, -f.z, 0), (-eye.s, -eye.u, eye.f, 1) = (-1,0,0,0), (0,1,0,0), (0,0,-1,0),
+    (0,0,-2,1).  proj = diag(a k, k, -1, 1) with k = 1 / tan(45 degrees) and -- the reference's quirk -- a = HEIGHT / WIDTH = 0.5.
+    camera = proj * view: columns (-a k, 0, 0, 0), (0, k, 0, 0), (0, 0, 1, 0), (0, 0, 2, 1); its inverse: (-1 / (a k), 0, 0, 0),
+    (0, 1 / k, 0, 0), (0, 0, 1, 0), (0, 0, -2, 1).  Everything but k is exact; k is 1 up to the rounding of tan."""
+    for cam, inv in (pkg.camera_matrices((0.0, 0.0, -2.0), (0.0, 0.0, 1.0), 90.0, 200, 100), O.camera((0.0, 0.0, -2.0), (0.0, 0.0, 1.0), 90.0, 200.0, 100.0)):
+        k = float(cam[5])
+        assert abs(k - 1.0) < 1e-6
+        assert cam.tolist() == [np.float32(-0.5 * k), 0, 0, 0, 0, np.float32(k), 0, 0, 0, 0, 1, 0, 0, 0, 2, 1]
+        assert inv[[1, 2, 3, 4, 6, 7, 8, 9, 11, 12, 13]].tolist() == [0] * 11 and inv[[10, 14, 15]].tolist() == [1, -2, 1]
+        assert abs(float(inv[0]) * (-0.5 * k) - 1.0) < 1e-6 and abs(float(inv[5]) * k - 1.0) < 1e-6
+        # the ray through the centre of the frame: origin = camera_inverse * (0, 0, 0, 1) = the eye, direction +z (shader.wgsl:54-59)
+        assert inv[12:15].tolist() == [0, 0, -2]
+
+
 def test_octree_subdivide_unsubdivide(pkg):
     """octree.rs:51-110: free-list reuse, panics as exceptions, pos_offset KAT 2."""
     V = pkg.Voxel
