@@ -350,10 +350,13 @@ def main():
         if pipelined:
             # (5) one GPU, the same frame, unsharded and serial (rank 0 alone, the others wait): what N GPUs are compared with
             if rank == 0:
-                e1, k1, _ = measure(W, H, k_extra, 3, a.wire, serial_one_gpu=True)
-                extras["one_gpu_same_workload"] = {"value": round(n_rays * k_extra / e1 / 1e6, 2), "unit": "Mrays/s", "steps": k_extra,
-                                                   "ms_per_step": round(e1 / k_extra * 1e3, 4), "kernel_avg_ms": round(float(np.mean(k1)), 4),
-                                                   "what": "rank 0 traces the whole frame alone, frames serial, same run"}
+                try:  # (rank 0 only, no collective inside: a failure here must not keep the other ranks waiting at the barrier below)
+                    e1, k1, _ = measure(W, H, k_extra, 3, a.wire, serial_one_gpu=True)
+                    extras["one_gpu_same_workload"] = {"value": round(n_rays * k_extra / e1 / 1e6, 2), "unit": "Mrays/s", "steps": k_extra,
+                                                       "ms_per_step": round(e1 / k_extra * 1e3, 4), "kernel_avg_ms": round(float(np.mean(k1)), 4),
+                                                       "what": "rank 0 traces the whole frame alone, frames serial, same run"}
+                except Exception as ex:  # noqa: BLE001
+                    extras["one_gpu_same_workload"] = {"error": repr(ex)}
             barrier()
             # (6) what the links allow: every ray's wire bytes end on rank 0, (N - 1) / N of them over rank 0's N - 1 inbound
             # xGMI links, one peer per link (7 links per GPU, ~64 GB/s per link and direction sustained: DESIGN.md 7)
