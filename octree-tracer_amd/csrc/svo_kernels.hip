@@ -517,9 +517,9 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
             // slot of level lvl + 1; a descent that starts on a leaf above level K+1 (from the top table) pushes its
             // one dead word into row 0, which is rewritten before any restart can read it
             uint32_t sp = (uint32_t)TBL + (max(lvl, (uint32_t)(SBASE - 1)) - (uint32_t)(SBASE - 1)) * BLOCK + tid;
-            // straight-line body, one exit test: the push also happens on the exiting iteration (it lands in the
-            // slot below the leaf, which no restart reads; the stack has one spare row for an exit at level SMAX)
-            do {
+            // The loop is rotated: a word is read, then looked at -- a leaf, or level SMAX, ends the walk BEFORE anything is pushed for
+            // it (the push of the exiting iteration landed below the leaf, where no restart reads: one LDS store per walk for nothing)
+            auto step_down = [&]() {
                 if (DBG) {
                     const uint64_t in_loop = __ballot(true);
                     if (lane == (uint32_t)__ffsll((unsigned long long)in_loop) - 1u) {  // (tallies summed over lanes at the end)
@@ -542,12 +542,16 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                     : "v"(ix), "v"(iy), "v"(iz), "v"(nidx));
                 w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
                 if (CNT) satm |= ((w & 15u) == 15u ? 1u : 0u) << ((uint32_t)D - sh);  // (a counter never goes down within a frame)
+                // sign bit: a leaf (word >= VOXEL_OFFSET << 4), or level SMAX reached (deeper trees are refused)
+                key = w | (sh - (uint32_t)(D - SMAX + 1));
+            };
+            step_down();
+            while ((int32_t)key >= 0) {
                 nidx = w >> 4;
                 lds[sp] = nidx;
                 sp += BLOCK;
-                // sign bit: a leaf (word >= VOXEL_OFFSET << 4), or level SMAX reached (deeper trees are refused)
-                key = w | (sh - (uint32_t)(D - SMAX + 1));
-            } while ((int32_t)key >= 0);
+                step_down();
+            }
             lvl = (uint32_t)D - sh;
             leaf_off = off;
             leaf_w = w;
