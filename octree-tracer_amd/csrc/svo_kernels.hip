@@ -288,23 +288,79 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
     uint32_t *cq = pool_all + (BLOCK / 64) * (kPoolWords * 64) + (tid >> 6) * kCountQueue;  // (CNT only: the launch allocates both)
     uint32_t *sat_tags = pool_all + (BLOCK / 64) * (kPoolWords * 64) + (BLOCK / 64) * kCountQueue;
     auto sat_slot = [](uint32_t p) -> uint32_t { return (p * 2654435761u) >> 23; };  // kSatTags = 512
+    // ... and what the table said about the words of levels 1..K -- which the walk never reads -- is kept per level-K cell (4 bits
+    // each: bit l = the level-l word on the way to this cell is saturated): every ray picked up and every ray that crosses a
+    // level-K boundary would otherwise look those words up one level per loop iteration (half of the loop's iterations), and a
+    // direct-mapped table forgets
+    uint32_t *top_sat = sat_tags + kSatTags;  // TBL / 8 words
     if (CNT) {
         for (uint32_t i = tid; i < (uint32_t)kSatTags; i += BLOCK) sat_tags[i] = 0xFFFFFFFFu;
+        for (uint32_t i = tid; i < (uint32_t)(TBL / 8); i += BLOCK) top_sat[i] = 0u;
         __syncthreads();
     }
     uint32_t cq_n = 0u;
+    // A flush takes the whole queue, two records per lane.  Four in ten of 64 consecutive records name a word that another
+    // of them names too (the same leaf or ancestor visited in consecutive rounds, or by lanes that were not neighbours): as
+    // two compare-and-swaps of one wave on one word, the second is bound to fail and costs the wave another round trip.
+    // So the records are merged first, in a hash table of the wave that lives in the queue's own 128 words (the records
+    // are in registers by then; more LDS would cost the fifth workgroup per CU): the first record of a word claims an entry,
+    // the others add their visits to it (saturating at 15, which is all a counter can take) and drop out; a record that
+    // finds neither its word nor a free entry within four probes goes alone -- correct, just not merged.  The device-scope
+    // loads of both halves travel together, and so do their compare-and-swaps.
+    static_assert(kCountQueue == 128, "the flush holds the queue in two registers per lane");
     auto cq_flush = [&]() {
-        for (uint32_t base = 0u; base < cq_n; base += 64u) {
-            const uint32_t i = base + (tid & 63u);
-            if (i < cq_n) {
-                const uint32_t rec = cq[i];
-                const uint32_t p = rec & 0x07FFFFFFu;
-                // (a device-scope load: the copy in this XCD's L2 is as old as its last miss, and a stale word costs a failed
-                // compare-and-swap -- the memory side's atomic rate, 24 G/s for the whole device, is what this mode runs against)
-                const uint32_t fresh = __hip_atomic_load(a.count_nodes + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (count_add(a.count_nodes, p, fresh, rec >> 27) == 15u) sat_tags[sat_slot(p)] = p;
+        constexpr uint32_t kFree = 0xFFFFFFFFu, kWord = 0x07FFFFFFu;
+        const bool v0 = lane < cq_n, v1 = 64u + lane < cq_n;
+        const uint32_t rec0 = v0 ? cq[lane] : 0u, rec1 = v1 ? cq[64u + lane] : 0u;
+        cq[lane] = kFree;
+        cq[64u + lane] = kFree;
+        // returns the visits to report for this record (0: another record of the wave reports them)
+        auto merge_in = [&](bool valid, uint32_t rec, uint32_t &slot) -> bool {  // true: this lane reports the word
+            const uint32_t p = rec & kWord;
+            slot = (p * 2654435761u) >> 25;
+            uint32_t role = valid ? 0u : 3u;  // 0: alone so far, 1: claimed an entry, 2: its word has an entry, 3: no record
+            uint32_t seen = 0u;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (role == 0u) {
+                    seen = atomicCAS(&cq[slot], kFree, rec);
+                    if (seen == kFree) role = 1u;
+                    else if ((seen & kWord) == p) role = 2u;
+                    else slot = (slot + 1u) & 127u;
+                }
             }
-        }
+            if (role == 2u) {
+                for (;;) {
+                    const uint32_t sum = min(15u, (seen >> 27) + (rec >> 27));
+                    const uint32_t want = p | (sum << 27);
+                    if (want == seen) break;
+                    const uint32_t got = atomicCAS(&cq[slot], seen, want);
+                    if (got == seen) break;
+                    seen = got;
+                }
+            }
+            if (role == 0u) slot = 0xFFFFFFFFu;  // alone: its own visits
+            return role <= 1u;
+        };
+        uint32_t slot0, slot1;
+        const bool i0 = merge_in(v0, rec0, slot0), i1 = merge_in(v1, rec1, slot1);
+        const uint32_t p0 = rec0 & kWord, p1 = rec1 & kWord;
+        const uint32_t n0 = (i0 && slot0 != 0xFFFFFFFFu) ? cq[slot0] >> 27 : rec0 >> 27;
+        const uint32_t n1 = (i1 && slot1 != 0xFFFFFFFFu) ? cq[slot1] >> 27 : rec1 >> 27;
+        // (device-scope loads: the copy in this XCD's L2 is as old as its last miss, and a stale word costs a failed
+        // compare-and-swap -- the memory side's atomic rate, 24 G/s for the whole device, is what this mode runs against)
+        const uint32_t f0 = i0 ? __hip_atomic_load(a.count_nodes + p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 15u;
+        const uint32_t f1 = i1 ? __hip_atomic_load(a.count_nodes + p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 15u;
+        const bool t0 = (f0 & 15u) < 15u, t1 = (f1 & 15u) < 15u;
+        const uint32_t a0 = min(n0, 15u - (f0 & 15u)), a1 = min(n1, 15u - (f1 & 15u));
+        uint32_t s0 = f0, s1 = f1;
+        if (t0) s0 = atomicCAS(&a.count_nodes[p0], f0, f0 + a0);
+        if (t1) s1 = atomicCAS(&a.count_nodes[p1], f1, f1 + a1);
+        uint32_t c0 = !t0 ? 15u : (s0 == f0 ? (f0 & 15u) + a0 : 16u), c1 = !t1 ? 15u : (s1 == f1 ? (f1 & 15u) + a1 : 16u);
+        if (c0 == 16u) c0 = count_add(a.count_nodes, p0, s0, n0);  // (somebody else's visit came in between)
+        if (c1 == 16u) c1 = count_add(a.count_nodes, p1, s1, n1);
+        if (i0 && c0 == 15u) sat_tags[sat_slot(p0)] = p0;
+        if (i1 && c1 == 15u) sat_tags[sat_slot(p1)] = p1;
         cq_n = 0u;
     };
     // all lanes call this (uniform control flow); `mine` = the lane has a visit of word p (value `word`) to report
@@ -866,6 +922,13 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
             if (__ballot(at_leaf) != 0ull) {
                 const uint32_t L = (st >> ST_L_SHIFT) & 31u;
                 uint32_t todo = at_leaf ? (~satm & ((1u << L) - 2u)) : 0u;  // levels 1 .. L-1 not known to be saturated
+                constexpr uint32_t kTopLv = (2u << K) - 2u;  // levels 1 .. K
+                const uint32_t cellK = (((uint32_t)ix >> (D - K)) << (2 * K)) | (((uint32_t)iy >> (D - K)) << K) | ((uint32_t)iz >> (D - K));
+                if (__ballot((todo & kTopLv) != 0u) != 0ull) {  // (rays picked up, rays that crossed a top-level boundary)
+                    const uint32_t known = (todo & kTopLv) ? ((top_sat[cellK >> 3] >> ((cellK & 7u) * 4u)) & todo & kTopLv) : 0u;
+                    satm |= known;
+                    todo &= ~known;
+                }
                 while (__ballot(todo != 0u) != 0ull) {
                     bool mine = todo != 0u;
                     const uint32_t l = mine ? (uint32_t)__builtin_ctz(todo) : 1u;
@@ -884,6 +947,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                     if (mine && sat_tags[sat_slot(p)] == p) {  // some lane of the workgroup has seen it reach 15
                         satm |= 1u << l;
                         mine = false;
+                        if (l <= (uint32_t)K) atomicOr(&top_sat[cellK >> 3], (1u << l) << ((cellK & 7u) * 4u));
                     }
                     cq_push(mine, p, 0u);
                 }
@@ -1452,7 +1516,7 @@ static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipS
                                          : (et ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false, true>
                                                : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false, false>)));
     size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
-                                (args.count_nodes ? (kStackBlock / 64) * kCountQueue + kSatTags : 0)) * sizeof(uint32_t);
+                                (args.count_nodes ? (kStackBlock / 64) * kCountQueue + kSatTags + (1 << (3 * kTopLevels)) / 8 : 0)) * sizeof(uint32_t);
     // cached per context (= per device): [deep stack?][fused shadows?][counting instantiation?]
     int &blocks_per_cu = li.occupancy[(args.debug ? 16 : 0) + (et ? 8 : 0) + (NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
     if (blocks_per_cu == 0) {
