@@ -52,16 +52,20 @@ __device__ __forceinline__ uint32_t count_add(uint32_t *nodes, uint32_t p, uint3
 // (no loop; two runs on one word then cost two atomics, which is still correct).
 // visit_groups: the number of visits this lane reports for word p -- the size of its group on the group's first lane, 0 on
 // every other lane (and on lanes whose word is saturated or outside the buffer).
+// RUNS_ONLY: every run is its own group whatever their number (the STACK kernel's queue merges equal words again before it
+// is flushed, so the exact grouping here would be paid twice).
+template <bool RUNS_ONLY = false>
 __device__ __forceinline__ uint32_t visit_groups(uint32_t n_words, uint32_t p, uint32_t word) {
     const bool need = p < n_words && (word & 15u) < 15u;
     const uint64_t needmask = __ballot(need);
     if (!needmask) return 0u;
     const uint32_t lane = __lane_id();
-    const uint32_t prev = (uint32_t)__shfl_up((int)p, 1);  // only looked at when lane - 1 is in needmask
+    // p of lane - 1 (DPP wave_shr:1: a shuffle through the LDS pipe costs its latency); only looked at when lane - 1 is in needmask
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x138, 0xF, 0xF, false);
     const bool head = need && (lane == 0u || !((needmask >> (lane - 1u)) & 1ull) || prev != p);
     const uint64_t headmask = __ballot(head);
     uint32_t n = 0u;  // visits this lane reports: the size of its group on the group's first lane, 0 elsewhere
-    if (__popcll(headmask) <= 8) {
+    if (!RUNS_ONLY && __popcll(headmask) <= 8) {
         uint64_t todo = headmask;
         while (todo) {
             const uint32_t leader = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
     };
     // all lanes call this (uniform control flow); `mine` = the lane has a visit of word p (value `word`) to report
     auto cq_push = [&](bool mine, uint32_t p, uint32_t word) {
-        const uint32_t n = visit_groups(a.n_words, p, mine ? word : 15u);
+        const uint32_t n = visit_groups<true>(a.n_words, p, mine ? word : 15u);
         const uint64_t m = __ballot(n != 0u);
         if (!m) return;
         if (cq_n > (uint32_t)kCountQueue - 64u) {
@@ -929,6 +933,9 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                     satm |= known;
                     todo &= ~known;
                 }
+                // (bit 0: the leaf itself -- word and address are at hand.  It takes its turn in the loop like a level: lanes
+                // report different words in one pass anyway, and a pass of its own for the leaf cost a third of the step)
+                todo |= (at_leaf && (leaf_w & 15u) < 15u) ? 1u : 0u;
                 while (__ballot(todo != 0u) != 0ull) {
                     bool mine = todo != 0u;
                     const uint32_t l = mine ? (uint32_t)__builtin_ctz(todo) : 1u;
@@ -938,21 +945,20 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                     uint32_t g = 0u;
                     if (l >= (uint32_t)SBASE) {
                         g = lds[(uint32_t)TBL + (l - (uint32_t)SBASE) * BLOCK + tid];
-                    } else if (kk != 0u) {
+                    } else if (l >= 2u) {
                         const uint32_t cell = (((uint32_t)ix >> shc) << (2u * kk)) | (((uint32_t)iy >> shc) << kk) | ((uint32_t)iz >> shc);
                         g = kk == (uint32_t)K ? (tbl[cell] & 0x07FFFFFFu) : aux[(kk == 1u ? 0u : 8u) + cell];
                     }
                     const uint32_t bit = (uint32_t)D - l;
-                    const uint32_t p = g + ((((uint32_t)ix >> bit) & 1u) << 2 | (((uint32_t)iy >> bit) & 1u) << 1 | (((uint32_t)iz >> bit) & 1u));
+                    uint32_t p = g + ((((uint32_t)ix >> bit) & 1u) << 2 | (((uint32_t)iy >> bit) & 1u) << 1 | (((uint32_t)iz >> bit) & 1u));
+                    p = l == 0u ? leaf_off >> 2 : p;
                     if (mine && sat_tags[sat_slot(p)] == p) {  // some lane of the workgroup has seen it reach 15
-                        satm |= 1u << l;
+                        satm |= (1u << l) & ~1u;
                         mine = false;
-                        if (l <= (uint32_t)K) atomicOr(&top_sat[cellK >> 3], (1u << l) << ((cellK & 7u) * 4u));
+                        if (l - 1u < (uint32_t)K) atomicOr(&top_sat[cellK >> 3], (1u << l) << ((cellK & 7u) * 4u));
                     }
                     cq_push(mine, p, 0u);
                 }
-                // the leaf itself: word and address are at hand
-                cq_push(at_leaf && sat_tags[sat_slot(leaf_off >> 2)] != (leaf_off >> 2), leaf_off >> 2, leaf_w);
             }
             if (DBG) dbg_desc_start += (uint32_t)(__builtin_amdgcn_s_memtime() - c_c0);  // (CNT: slot 15 = cycles spent counting)
         }
