@@ -291,7 +291,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
     // hundreds of later visits of a word near the root cost one LDS read each, on whichever lane and ray they happen.
     uint32_t *cq = pool_all + (BLOCK / 64) * (kPoolWords * 64) + (tid >> 6) * kCountQueue;  // (CNT only: the launch allocates both)
     uint32_t *sat_tags = pool_all + (BLOCK / 64) * (kPoolWords * 64) + (BLOCK / 64) * kCountQueue;
-    auto sat_slot = [](uint32_t p) -> uint32_t { return (p * 2654435761u) >> 23; };  // kSatTags = 512
+    auto sat_slot = [](uint32_t p) -> uint32_t { return (p ^ (p >> 9)) & 511u; };  // kSatTags = 512 (no multiply: quarter rate)
     // ... and what the table said about the words of levels 1..K -- which the walk never reads -- is kept per level-K cell (4 bits
     // each: bit l = the level-l word on the way to this cell is saturated): every ray picked up and every ray that crosses a
     // level-K boundary would otherwise look those words up one level per loop iteration (half of the loop's iterations), and a
@@ -927,8 +927,11 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                 const uint32_t L = (st >> ST_L_SHIFT) & 31u;
                 uint32_t todo = at_leaf ? (~satm & ((1u << L) - 2u)) : 0u;  // levels 1 .. L-1 not known to be saturated
                 constexpr uint32_t kTopLv = (2u << K) - 2u;  // levels 1 .. K
-                const uint32_t cellK = (((uint32_t)ix >> (D - K)) << (2 * K)) | (((uint32_t)iy >> (D - K)) << K) | ((uint32_t)iz >> (D - K));
+                auto cell_k = [&]() -> uint32_t {
+                    return (((uint32_t)ix >> (D - K)) << (2 * K)) | (((uint32_t)iy >> (D - K)) << K) | ((uint32_t)iz >> (D - K));
+                };
                 if (__ballot((todo & kTopLv) != 0u) != 0ull) {  // (rays picked up, rays that crossed a top-level boundary)
+                    const uint32_t cellK = cell_k();
                     const uint32_t known = (todo & kTopLv) ? ((top_sat[cellK >> 3] >> ((cellK & 7u) * 4u)) & todo & kTopLv) : 0u;
                     satm |= known;
                     todo &= ~known;
@@ -949,13 +952,17 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                         const uint32_t cell = (((uint32_t)ix >> shc) << (2u * kk)) | (((uint32_t)iy >> shc) << kk) | ((uint32_t)iz >> shc);
                         g = kk == (uint32_t)K ? (tbl[cell] & 0x07FFFFFFu) : aux[(kk == 1u ? 0u : 8u) + cell];
                     }
-                    const uint32_t bit = (uint32_t)D - l;
-                    uint32_t p = g + ((((uint32_t)ix >> bit) & 1u) << 2 | (((uint32_t)iy >> bit) & 1u) << 1 | (((uint32_t)iz >> bit) & 1u));
+                    const uint32_t bit = (uint32_t)D - l;  // (l = 0: bit 24 of a 24-bit code, i.e. 0 -- and p is replaced below)
+                    uint32_t p = g + ((__builtin_amdgcn_ubfe((uint32_t)ix, bit, 1u) << 2) | (__builtin_amdgcn_ubfe((uint32_t)iy, bit, 1u) << 1) |
+                                      __builtin_amdgcn_ubfe((uint32_t)iz, bit, 1u));
                     p = l == 0u ? leaf_off >> 2 : p;
                     if (mine && sat_tags[sat_slot(p)] == p) {  // some lane of the workgroup has seen it reach 15
                         satm |= (1u << l) & ~1u;
                         mine = false;
-                        if (l - 1u < (uint32_t)K) atomicOr(&top_sat[cellK >> 3], (1u << l) << ((cellK & 7u) * 4u));
+                        if (l - 1u < (uint32_t)K) {
+                            const uint32_t cellK = cell_k();
+                            atomicOr(&top_sat[cellK >> 3], (1u << l) << ((cellK & 7u) * 4u));
+                        }
                     }
                     cq_push(mine, p, 0u);
                 }

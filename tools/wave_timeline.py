@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--h", type=int, default=1080)
     ap.add_argument("--json", default=None)
     ap.add_argument("--count", action="store_true", help="hit counters live, cleared before the frame (the reference's default mode)")
+    ap.add_argument("--carry", action="store_true", help="with --count: the counters carry over from frame to frame (no scan in between)")
     ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE for gpu.set_option (e.g. REFILL_MIN=8)")
     a = ap.parse_args()
     pkg = entry.load_package()
@@ -46,7 +47,7 @@ def main():
         gpu.set_option(pkg.gpu.OPT_SCAN_CLEARS_COUNTERS, 1)
 
     def clear():
-        if a.count:
+        if a.count and not a.carry:
             compute.update(int(words.size)); compute.read_lists()
     render.update(pkg.Settings(), pkg.Character(*pose))
     for o in a.opt:
@@ -55,7 +56,7 @@ def main():
     dbg = torch.zeros((16384, 16), dtype=torch.int32, device="cuda")
     hits = render.alloc_hits(W * H)
     gpu.set_option(pkg.gpu.OPT_TIMING, 8)
-    for _ in range(4):
+    for _ in range(8 if a.carry else 4):
         clear()
         render.render(hits=hits)
     ms_plain = gpu.last_render_ms()
