@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=30)
 ap.add_argument("--fused", type=int, default=2)
 ap.add_argument("--carry", action="store_true", help="counters carry over from frame to frame (no scan between frames)")
+ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE for gpu.set_option (e.g. REFILL_MIN=8)")
 a = ap.parse_args()
 pkg = entry.load_package()
 import torch  # noqa: E402
@@ -28,6 +29,9 @@ gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
 gpu.set_option(pkg.gpu.OPT_SCAN_CLEARS_COUNTERS, 1)
 gpu.set_option(pkg.gpu.OPT_FUSED_SHADOWS, a.fused)
 gpu.set_option(pkg.gpu.OPT_TIMING, 4)
+for o in a.opt:
+    k, v = o.split("=")
+    gpu.set_option(getattr(pkg.gpu, "OPT_" + k), int(v))
 W, H = 1920, 1080
 render = pkg.Render(gpu, (W, H), words, capacity=words.size)
 compute = pkg.Compute.new(gpu, render)
