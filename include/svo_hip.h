@@ -89,16 +89,9 @@ typedef struct svo_ctx svo_ctx;
 /* kernel variants (svo_set_option SVO_OPT_VARIANT) */
 #define SVO_VARIANT_RESTART 0 /* reference-shaped: float-compare descent from the root every step */
 #define SVO_VARIANT_STACK 1   /* integer path codes + per-ray ancestor stack in LDS + LDS top table + refill (default) */
-/* Two experiments of round 3, kept selectable and under the same parity tests (neither is faster on the benchmark
- * frame -- the traversal is bound by instruction issue, not by its dependent loads).  Both walk a device-built table with one word
- * per node word (its child group and which of the 8 children are empty leaves, so a step into an empty leaf needs no load; as much
- * device memory as the node buffer, rebuilt by the first such trace after the words changed: one pass over the array and one host
- * synchronisation) and apply to static trees (pause_adaptive, or caller-supplied rays); arrays whose child groups are not
- * 8-aligned inside the buffer (Octree::subdivide always makes them so, octree.rs:72-90) and every other mode run SVO_VARIANT_STACK.
- * Results do not depend on the variant. */
-#define SVO_VARIANT_ETAB 2    /* the STACK kernel over that table: half the dependent loads */
-#define SVO_VARIANT_DUAL 3    /* two rays per lane, software-pipelined: one ray's load travels while the lane's other ray steps
-                                 (trees of depth <= 16, no fused shadow rays; otherwise as SVO_VARIANT_ETAB) */
+/* (Round 3's two experiments over a device-built child-mask table -- one ray per lane, and two rays per lane software-pipelined --
+ * measured slower than SVO_VARIANT_STACK on every scene and left the library in round 4; the source is kept under
+ * tools/experiments/ with its logs in profiles/r03_*, DESIGN.md 4.8.  Values 2 and 3 are refused.) */
 
 typedef enum svo_option {
     SVO_OPT_VARIANT = 0,
@@ -122,8 +115,7 @@ typedef enum svo_option {
                                    on with that pixel's shadow ray inside the primary launch; 0 = shadow rays are a second launch;
                                    2 (default) = automatic, which fuses whenever the sun direction is one the fast arithmetic covers
                                    (1080p: 0.65 -> 0.58 ms, 4K: 2.04 -> 1.78 ms on the benchmark tree).  The image is the same either way. */
-    SVO_OPT_PAIR_TABLE = 13, /* accepted and ignored: the two-levels-per-load table of round 2 measured a net loss and left the library;
-                                the child-mask table of SVO_VARIANT_ETAB took its place */
+    SVO_OPT_PAIR_TABLE = 13, /* accepted and ignored: the two-levels-per-load table of round 2 measured a net loss and left the library */
     SVO_OPT_CULL = 14,       /* pixel frames, STACK variant: 64-pixel blocks whose rays all miss the cube (decided conservatively from
                                 the block's corner rays) get their all-zero records from a pre-pass and are never claimed by the
                                 trace.  0 off, 1 whenever the camera is outside the cube, 2 (default) when in addition at least 40 % of a

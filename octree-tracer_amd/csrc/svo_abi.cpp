@@ -70,10 +70,6 @@ void release_store(svo_ctx *ctx) {
     if (!st || --st->refs > 0) return;
     (void)hipSetDevice(st->device);
     if (st->nodes && st->owned) (void)hipFree(st->nodes);
-    if (st->etab) (void)hipFree(st->etab);
-    if (st->etop) (void)hipFree(st->etop);
-    if (st->etab_flag) (void)hipFree(st->etab_flag);
-    if (st->etab_ready) (void)hipEventDestroy(st->etab_ready);
     if (st->last_write) (void)hipEventDestroy(st->last_write);
     delete st;
 }
@@ -91,50 +87,6 @@ int ensure_top_table(svo_ctx *ctx) {
     if (rc) return rc;
     HIP_TRY(ctx, svo::launch_build_top_table(ctx->nodes, (uint32_t)ctx->capacity, ctx->top_table, ctx->stream));
     ctx->top_version = ctx->store->version;
-    return SVO_OK;
-}
-
-// The E table of the store (svo_dual.hip), built by the first static trace after the words changed; *ok stays false when the
-// table does not fit (address range or free memory) or the array has child groups it cannot name (unaligned or past the
-// buffer: the builder says so in a device word, read back once per build) -- the one-ray kernel then traces, same results.
-// (Traces other contexts still have in flight read the old table while it is rebuilt: like the node words themselves, a write
-// does not wait for them, see svo_nodes_share.)
-int ensure_etab(svo_ctx *ctx, bool *ok) {
-    *ok = false;
-    svo_node_store *st = ctx->store;
-    if (st->etab_failed || st->capacity == 0 || st->capacity > (size_t(1) << 27)) return SVO_OK;
-    if (st->etab_version != st->version) {
-        if (!st->etab) {
-            const size_t bytes = st->capacity * sizeof(uint32_t);
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (size_t(1) << 30) ||
-                hipMalloc((void **)&st->etab, bytes) != hipSuccess ||
-                hipMalloc((void **)&st->etop, 2 * svo::kTopEntries * sizeof(uint32_t)) != hipSuccess ||
-                hipMalloc((void **)&st->etab_flag, sizeof(uint32_t)) != hipSuccess) {
-                (void)hipGetLastError();
-                if (st->etab) (void)hipFree(st->etab);
-                if (st->etop) (void)hipFree(st->etop);
-                st->etab = st->etop = nullptr;
-                st->etab_failed = true;
-                return SVO_OK;
-            }
-        }
-        int rc = order_after_last_write(ctx);
-        if (rc) return rc;
-        HIP_TRY(ctx, hipMemsetAsync(st->etab_flag, 0, sizeof(uint32_t), ctx->stream));
-        HIP_TRY(ctx, svo::launch_build_etab(st->nodes, (uint32_t)st->capacity, st->etab, st->etop, st->etab_flag, ctx->stream));
-        uint32_t bad = 1;
-        HIP_TRY(ctx, hipMemcpyAsync(&bad, st->etab_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        st->etab_ok = bad == 0;
-        if (!st->etab_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&st->etab_ready, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventRecord(st->etab_ready, ctx->stream));
-        st->etab_builder = ctx->stream;
-        st->etab_version = st->version;
-    } else if (st->etab_builder != ctx->stream) {
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, st->etab_ready, 0));
-    }
-    *ok = st->etab_ok;
     return SVO_OK;
 }
 
@@ -220,19 +172,6 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     const bool debug_hits = (ctx->uniforms.flags & SVO_F_PAUSE_ADAPTIVE) && (ctx->uniforms.flags & SVO_F_SHOW_HITS);
     const bool stack = want_stack && !debug_hits;
     a.shadow_hits = stack ? opt.shadow_out : nullptr;
-    // SVO_VARIANT_ETAB / SVO_VARIANT_DUAL (experiments of round 3): static trees walked through the E table
-    // (svo_dual.hip: child group + which children are empty leaves), by the one-ray kernel or by the two-rays-per-lane kernel
-    bool dual = false;
-    if (stack && !counting && (ctx->variant == SVO_VARIANT_ETAB || ctx->variant == SVO_VARIANT_DUAL)) {
-        bool ok = false;
-        rc = ensure_etab(ctx, &ok);
-        if (rc) return rc;
-        if (ok) {
-            a.etab = ctx->store->etab;
-            a.top_table = ctx->store->etop;
-            dual = ctx->variant == SVO_VARIANT_DUAL && !a.shadow_hits && ctx->tree_depth <= (uint32_t)svo::dual_max_depth();
-        }
-    }
     const uint32_t n_strips = (wd.n_items + 63u) / 64u;
     const bool schedule = ctx->schedule && n_strips <= svo::kMaxScheduledStrips;
     svo_ctx::Sched &sc = ctx->sched[opt.sched_slot & 1];
@@ -278,7 +217,6 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
     li.strip_items = ctx->strip_items;
     li.deep_stack = ctx->tree_depth > (uint32_t)svo::stack_max_depth(false);
     li.occupancy = ctx->occupancy;
-    li.dual = dual;
     if (stack && ctx->defer_items < wd.n_items) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->defer_buf) (void)hipFree(ctx->defer_buf);
@@ -651,7 +589,7 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
     if (!ctx) return SVO_ERR_ARG;
     switch (option) {
         case SVO_OPT_VARIANT:
-            if (value != SVO_VARIANT_RESTART && value != SVO_VARIANT_STACK && value != SVO_VARIANT_ETAB && value != SVO_VARIANT_DUAL) return fail(ctx, SVO_ERR_ARG, "unknown variant");
+            if (value != SVO_VARIANT_RESTART && value != SVO_VARIANT_STACK) return fail(ctx, SVO_ERR_ARG, "unknown variant");
             ctx->variant = (int)value;
             return SVO_OK;
         case SVO_OPT_TIMING: {
@@ -712,7 +650,7 @@ int svo_set_option(svo_ctx *ctx, int option, int64_t value) {
             if (value < 0 || value > 2) return fail(ctx, SVO_ERR_ARG, "cull: 0 (off), 1 (whenever the camera is outside the cube) or 2 (automatic)");
             ctx->cull_mode = (int)value;
             return SVO_OK;
-        case SVO_OPT_PAIR_TABLE:  // (the table left the library; the E table of svo_dual.hip took its place)
+        case SVO_OPT_PAIR_TABLE:  // (the table left the library in round 3)
             return SVO_OK;
         case SVO_OPT_DEBUG_BUFFER:
             ctx->debug_buf = (uint32_t *)(uintptr_t)value;  // device pointer, 64 B per wave of the grid; 0 = off
@@ -741,10 +679,6 @@ int svo_sync(svo_ctx *ctx) {
     // surface device-side errors raised by trace kernels
     uint32_t st = 0;
     HIP_TRY(ctx, hipMemcpy(&st, ctx->status, sizeof(st), hipMemcpyDeviceToHost));
-    if (st & 4u) {  // (bring-up builds of the two-ray kernel only: SVO_DUAL_GUARD)
-        HIP_TRY(ctx, hipMemset(ctx->status, 0, sizeof(uint32_t)));
-        return fail(ctx, SVO_ERR_STATE, "a wave of the two-ray kernel ran into its iteration guard");
-    }
     if (st & 2u) {
         HIP_TRY(ctx, hipMemset(ctx->status, 0, sizeof(uint32_t)));
         return fail(ctx, SVO_ERR_STATE, "fused shadow ray outside the range of the fast arithmetic (set SVO_OPT_FUSED_SHADOWS to 0)");

@@ -23,14 +23,6 @@ struct svo_node_store {
     uint64_t version = 1;        // bumped whenever the words may have changed
     hipEvent_t last_write = nullptr;   // recorded on the writing context's stream after every write
     hipStream_t last_writer = nullptr; // that stream: other streams wait for the event before they read
-    // E table of the dual kernel (svo_dual.hip): one word per node word + the top table made from it (2 * kTopEntries words)
-    uint32_t *etab = nullptr, *etop = nullptr;
-    uint32_t *etab_flag = nullptr;   // device word: the builder found a child group the table cannot name
-    uint64_t etab_version = 0;   // store version the table was built from (0: never)
-    bool etab_ok = false;        // that version is traceable through the table
-    bool etab_failed = false;    // allocation failed once: stay on the one-ray kernel
-    hipEvent_t etab_ready = nullptr;   // recorded behind the build on the building context's stream
-    hipStream_t etab_builder = nullptr;
 };
 
 struct svo_ctx {
@@ -65,7 +57,7 @@ struct svo_ctx {
     // options
     int variant = SVO_VARIANT_STACK;
     int grid_blocks = 0;
-    int occupancy[32] = {};  // resident workgroups per CU of each STACK instantiation on this device (0: not asked yet)
+    int occupancy[16] = {};  // resident workgroups per CU of each STACK instantiation on this device (0: not asked yet)
     uint32_t refill_min = 16;
     bool scan_clears = false;
     int fused_shadows = 2;  // 0: off, 1: on, 2: by frame size and tree depth (see trace_common)

@@ -40,8 +40,6 @@ struct TraceArgs {
     const uint32_t *nodes;
     uint32_t n_words;
     const uint32_t *top_table;  // kTopEntries words (device) or nullptr
-    const uint32_t *etab;       // dual kernel: the E table, one word per node word (child group + empty-mask, svo_dual.hip); its
-                                // top table (2 * kTopEntries words) is then what `top_table` points to
     svo_uniforms u;
     WorkDesc work;
     const float *rays;          // mode 2
@@ -66,7 +64,6 @@ struct LaunchInfo {
     int num_cus;
     int *occupancy;          // STACK: the context's cache of resident workgroups per CU, one slot per instantiation
     bool deep_stack;         // STACK: 19-level ancestor stack (trees deeper than 16 levels)
-    bool dual;               // STACK: two rays per lane over the E table (args.etab, args.top_table = its top table)
     uint32_t strip_items;    // STACK: pixel slots a wave claims at a time (multiple of 64)
     uint32_t *counters;      // STACK: kCounterWords claim-counter words, zero when a frame starts
     uint32_t *work_counter;  // STACK: counters + 0 for dynamic strip claiming, or nullptr (static round-robin)
@@ -76,12 +73,6 @@ struct LaunchInfo {
 
 hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint32_t *top_table,
                                   hipStream_t stream);
-// svo_dual.hip: E table (n_words words), its top table (2 * kTopEntries words) and the flag word that says the array has child
-// groups the table cannot name (then the one-ray kernel traces it)
-hipError_t launch_build_etab(const uint32_t *nodes, uint32_t n_words, uint32_t *etab, uint32_t *etop, uint32_t *flag, hipStream_t stream);
-// two rays per lane over the E table: static trees (no hit counting), no fused shadow rays, depth <= dual_max_depth()
-hipError_t launch_trace_dual(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream);
-int dual_max_depth();
 hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream);
 int stack_max_depth(bool deep);
 // after a STACK trace: deferred rays, per-strip costs (cost != nullptr) and the next schedule; re-arms the counters

@@ -241,17 +241,13 @@ __global__ __launch_bounds__(256) void build_top_table_kernel(const uint32_t *no
 // a clean ray), so  A = (C - P) + H,  t = A / Dr,  G = (P + Dr * t) +- K  are exactly 2^23 times the
 // reference's  a,  the same t,  and  2^23 * voxel_pos  -- and G is what the path codes need.
 // CNT: hit counters live (adaptive mode, shader.wgsl:157-161), see step 3a in the loop.
-// ET: walk the E table of svo_dual.hip instead of the node words (static trees): an entry names a child group AND which of its
-// children are empty leaves, so the walk ends one load earlier -- at the group, not at the leaf word -- whenever the ray's leaf is
-// empty, which is the case at nearly every DDA step; a step between siblings needs no load at all.
-template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD, bool ET>
+template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD>
 __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
     constexpr int SMAX = K + 1 + NS;   // last level kept on the LDS stack = deepest level resolved
     static_assert(SMAX <= D - 1, "stack deeper than the path codes");
-    static_assert(!(ET && CNT), "the counting instantiation walks (and counts in) the node words themselves");
     constexpr int TBL = 1 << (3 * K);
     constexpr float kScale = 8388608.0f;  // 2^23
     constexpr float kInvScale = 1.0f / 8388608.0f;
@@ -462,41 +458,16 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
     // knows leaves that cover a whole level-K cell), else from the lane's ancestor stack.  One LDS read.
     auto restart_at = [&](uint32_t r) {
         const bool top = r <= (uint32_t)(K + 1);
-        uint32_t addr = (uint32_t)TBL + (r - SBASE) * BLOCK + tid;
+        const uint32_t addr = (uint32_t)TBL + (r - SBASE) * BLOCK + tid;
         if (__ballot(top)) {  // wave-uniform: most rounds no lane crosses a level-(K+1) boundary
             const uint32_t cell = ((uint32_t)(ix >> (D - K)) << (2 * K)) | ((uint32_t)(iy >> (D - K)) << K) |
                                   (uint32_t)(iz >> (D - K));
-            addr = top ? cell : addr;
-        }
-        const uint32_t e = lds[addr];
-        if (ET) {
-            // an E entry: the child group of the restart level and which of its children are empty leaves -- or, from the top
-            // table, the marker of a leaf that covers the whole level-K cell.  The child the position selects is looked at HERE:
-            // an empty leaf needs no walk at all (the ray is at its leaf: ST_DESC is dropped), else nidx = byte offset of the
-            // child's entry, which descend_et reads.
-            constexpr uint32_t kMark = 0xFFFFFF00u;  // (kEMark of svo_dual.hip)
-            uint32_t L = top ? (uint32_t)(K + 1) : r;
-            bool at_leaf;
-            if (top && e >= kMark) {
-                L = (e >> 1) & 3u;
-                at_leaf = true;
-                leaf_w = (kVoxelOffset + (e & 1u)) << 4;
-                if (e & 1u) {
-                    const uint32_t cell = ((uint32_t)(ix >> (D - K)) << (2 * K)) | ((uint32_t)(iy >> (D - K)) << K) | (uint32_t)(iz >> (D - K));
-                    leaf_off = a.top_table[(uint32_t)TBL + cell] << 2;
-                }
-            } else {
-                const uint32_t shc = (uint32_t)D - L;
-                const uint32_t c = ((((uint32_t)ix >> shc) & 1u) << 2) | ((((uint32_t)iy >> shc) & 1u) << 1) | (((uint32_t)iz >> shc) & 1u);
-                at_leaf = ((e >> c) & 1u) != 0u;
-                if (at_leaf) leaf_w = kVoxelOffset << 4;
-                nidx = ((e >> 3) & ~31u) | (c << 2);
-            }
-            lvl = L;
-            if (at_leaf) st = (st & ~(ST_L_MASK | ST_DESC)) | (L << ST_L_SHIFT);
-        } else {
+            const uint32_t e = lds[top ? cell : addr];
             lvl = top ? (e >> 27) : r;
             nidx = e & 0x07FFFFFFu;
+        } else {  // a stack entry is the child group itself (< 2^27): nothing to unpack
+            lvl = r;
+            nidx = lds[addr];
         }
     };
 
@@ -618,59 +589,6 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
             st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
             };
 
-    // ET: the walk over the E table (svo_dual.hip).  restart_at has looked at the child of level lvl already: nidx is the byte
-    // offset of its entry.  An entry is a leaf marker (the leaf is solid: empty ones are known from their parent's mask), or the
-    // next child group with its empty-mask: the walk ends AT THE GROUP when the child the position selects there is an empty
-    // leaf.  What the step and the record need of the leaf word is synthesised: VOXEL_OFFSET << 4 for an empty leaf, a solid
-    // value otherwise, 0 for "still interior at level SMAX"; leaf_off is the byte offset of a solid leaf's word (= its node
-    // index << 2: the table is parallel to the array).
-    const rsrc_t re = ET ? make_rsrc(a.etab, a.n_words) : rs;
-    auto descend_et = [&]() {
-        constexpr uint32_t kMark = 0xFFFFFF00u;
-        uint32_t off = nidx, w;
-        uint32_t sh = (uint32_t)D - lvl;  // bit of the path codes that selects the child of the level being read
-        // row of level lvl + 1 (a walk that starts at level K + 1 = SBASE - 1 pushes into row 0)
-        uint32_t sp = (uint32_t)TBL + (lvl - (uint32_t)(SBASE - 1)) * BLOCK + tid;
-        for (;;) {
-            if (DBG) {
-                const uint64_t in_loop = __ballot(true);
-                if (lane == (uint32_t)__ffsll((unsigned long long)in_loop) - 1u) {
-                    dbg_desc_iters += 1u;
-                    dbg_desc_lanes += (uint32_t)__popcll(in_loop);
-                }
-            }
-            const uint32_t e = __builtin_amdgcn_raw_buffer_load_b32(re, (int)off, 0, 0);
-            lds[sp] = e;  // (also on the exiting iteration: that slot lies below the leaf, no restart reads it; one spare row)
-            sp += BLOCK;
-            if (e >= kMark) {  // the child is a leaf, and not an empty one
-                w = (kVoxelOffset + 1u) << 4;
-                break;
-            }
-            if (sh <= (uint32_t)(D - SMAX)) {  // still interior at level SMAX: deeper than this kernel resolves
-                w = 0u;
-                break;
-            }
-            uint32_t c, tmp;
-            asm("v_add_u32 %2, -1, %2\n\t"
-                "v_bfe_u32 %0, %3, %2, 1\n\t"
-                "v_bfe_u32 %1, %4, %2, 1\n\t"
-                "v_lshl_or_b32 %0, %0, 1, %1\n\t"
-                "v_bfe_u32 %1, %5, %2, 1\n\t"
-                "v_lshl_or_b32 %0, %0, 1, %1"
-                : "=&v"(c), "=&v"(tmp), "+v"(sh)
-                : "v"(ix), "v"(iy), "v"(iz));
-            if ((e >> c) & 1u) {  // an empty leaf one level further down
-                w = kVoxelOffset << 4;
-                break;
-            }
-            off = ((e >> 3) & ~31u) | (c << 2);
-        }
-        lvl = (uint32_t)D - sh;
-        leaf_off = off;
-        leaf_w = w;
-        st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
-    };
-
     // Camera shortcut.  Every primary ray of a camera that stands INSIDE the cube starts at the same point, hence in the
     // same leaf, with the same ancestors: the first walk of a ray -- the longest it ever makes, root to leaf, while the
     // other lanes of the wave wait for it -- is the same for all of them.  The wave makes it once, here, all lanes alike,
@@ -690,11 +608,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
             iz = entry_code<GE>(r0.pz * kScale);
             st = ST_ACTIVE | ST_DESC;
             restart_at(1u);
-            if (ET) {
-                if (st & ST_DESC) descend_et();
-            } else {
-                descend();
-            }
+            descend();
             uint32_t v = lane < (uint32_t)NS ? lds[(uint32_t)TBL + lane * BLOCK + tid] : 0u;  // row `lane` of this lane's own column
             v = lane == (uint32_t)NS ? leaf_off : v;
             v = lane == (uint32_t)NS + 1u ? leaf_w : v;
@@ -716,7 +630,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
         }
         // ---- 1. descent: one dependent word per level below the restart level ----
         if (st >= (ST_ACTIVE | ST_DESC)) {  // DESC implies ACTIVE: one unsigned compare
-            if (ET) descend_et(); else descend();
+            descend();
         }
         if (DBG) {
             const uint64_t now = __builtin_amdgcn_s_memtime();
@@ -1517,21 +1431,17 @@ template <bool GE, int NS>
 static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipStream_t stream) {
     const uint32_t strip_items = args.order ? 64u : (li.strip_items ? li.strip_items : 64u);
     const bool shd = args.shadow_hits != nullptr;  // fused shadow rays (no timeline build of that one)
-    const bool et = args.etab != nullptr;  // (the ABI passes the table only for static trees)
-    auto kern = shd ? (args.count_nodes ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, true, false>
-                                        : (et ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, true, true>
-                                              : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, true, false>))
+    auto kern = shd ? (args.count_nodes ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, true>
+                                        : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, true>)
                     : (args.count_nodes
-                           ? (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, true, false, false>
-                                         : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, false, false>)
-                           : (args.debug ? (et ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false, true>
-                                               : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false, false>)
-                                         : (et ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false, true>
-                                               : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false, false>)));
+                           ? (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, true, false>
+                                         : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, false>)
+                           : (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false>
+                                         : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false>));
     size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
                                 (args.count_nodes ? (kStackBlock / 64) * kCountQueue + kSatTags + (1 << (3 * kTopLevels)) / 8 : 0)) * sizeof(uint32_t);
     // cached per context (= per device): [deep stack?][fused shadows?][counting instantiation?]
-    int &blocks_per_cu = li.occupancy[(args.debug ? 16 : 0) + (et ? 8 : 0) + (NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
+    int &blocks_per_cu = li.occupancy[(args.debug ? 8 : 0) + (NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
     if (blocks_per_cu == 0) {
         int n = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kStackBlock, lds_bytes);
@@ -1569,7 +1479,6 @@ hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t
     }
     // li.counters = {8 claim counters (128 B apart), deferred-ray count, deferred items}: zero when a frame
     // starts (armed at allocation and re-armed by the last kernel of the previous frame)
-    if (li.dual) return launch_trace_dual(args, li, stream);
     const bool ge = (args.u.flags & SVO_F_MISC_BOOL) != 0;
     if (li.deep_stack)  // trees deeper than kTopLevels + 1 + kStackLevels: more LDS per workgroup, fewer resident waves
         return ge ? launch_stack<true, kStackLevelsDeep>(args, li, stream) : launch_stack<false, kStackLevelsDeep>(args, li, stream);

@@ -5,7 +5,7 @@ import ctypes as C
 from ._lib import SvoError, lib
 
 OPT_VARIANT, OPT_TIMING, OPT_GRID_BLOCKS, OPT_REFILL_MIN, OPT_STRIP_ITEMS, OPT_DYNAMIC_STRIPS, OPT_PRIO_STEPS, OPT_DEBUG_BUFFER, OPT_SCHEDULE, OPT_TREE_DEPTH, OPT_BLOCK_SHAPE, OPT_SCAN_CLEARS_COUNTERS, OPT_FUSED_SHADOWS, OPT_PAIR_TABLE, OPT_CULL, OPT_CAMERA_SHORTCUT, OPT_SCHEDULE_MOTION = range(17)
-VARIANT_RESTART, VARIANT_STACK, VARIANT_ETAB, VARIANT_DUAL = 0, 1, 2, 3
+VARIANT_RESTART, VARIANT_STACK = 0, 1
 
 
 class Gpu:

@@ -59,7 +59,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="2,3,5")
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--variant", type=int, default=1, help="1 STACK, 2 ETAB, 3 DUAL (svo_hip.h)")
+    ap.add_argument("--variant", type=int, default=1, help="0 RESTART, 1 STACK (svo_hip.h)")
     a = ap.parse_args()
     pkg, O = entry.load_package(), entry.load_oracle()
     import torch

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--count", action="store_true", help="adaptive mode: also compare the hit counters after each frame (slower: the oracle counts on one thread)")
     ap.add_argument("--secondary", action="store_true", help="svo_render_secondary with 4 rays per hit pixel, random sun directions, ray 0 fused into the primary launch (SVO_OPT_FUSED_SHADOWS = 1): primary and secondary records against the oracle")
     ap.add_argument("--cull", type=int, default=2, help="SVO_OPT_CULL (1: cull whenever the camera is outside the cube); every 8th pose then stands far away")
-    ap.add_argument("--variant", type=int, default=1, help="kernel variant (svo_hip.h): 1 STACK, 2 ETAB, 3 DUAL")
+    ap.add_argument("--variant", type=int, default=1, help="kernel variant (svo_hip.h): 0 RESTART, 1 STACK")
     ap.add_argument("--deep", action="store_true", help="deep trees instead (depth-20 fractal, depth-19 terrain): the 19-level stack instantiations, SVO_OPT_TREE_DEPTH = 20")
     a = ap.parse_args()
     pkg, O = entry.load_package(), entry.load_oracle()

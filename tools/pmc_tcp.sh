@@ -10,10 +10,10 @@ pass() {
 }
 pass t1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_TOTAL_WRITE_sum
 pass t2 TCP_TCP_LATENCY_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum
-# (Round 2: a pass with TA_* counters -- TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum TA_BUFFER_TOTAL_CYCLES_sum ... -- aborted inside rocprofv3 with
-# signal 6 on this image and then sat there until the silence guard killed the call; that pass ran without the `timeout` the passes above now
-# carry and its stderr was not kept, so the cause -- an unsupported counter or too many for one pass -- is not known.  The TCP passes above say
-# what DESIGN.md needs of the vector-memory pipeline; should TA_* be wanted, run ONE counter per pass under this `timeout` and keep the .err.)
+# (Round 2: a pass with five TA_* counters -- TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum TA_BUFFER_TOTAL_CYCLES_sum ... -- aborted inside
+# rocprofv3 with signal 6.  The cause is on record (gpurun_out/r02_tcp/t3.err of that round): "rocprofiler_create_counter_config ... failed
+# with error code 38: Request exceeds the capabilities of the hardware to collect" -- too many TA counters for one pass.  The abort is
+# rocprofv3's, before the program starts; the product never ran.  Should TA_* be wanted: ONE counter per pass, under the `timeout` above.)
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections, json
 out = sys.argv[1]

@@ -12,10 +12,9 @@ SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-fram
 g++ $SAN -std=c++17 -ffp-contract=off -fPIC -I"$ROOT/include" -c "$ROOT/octree-tracer_amd/csrc/svo_host.cpp" -o "$OUT/svo_host.o"
 HIPFLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -I$ROOT/include -Wno-unused-function"
 /opt/rocm/bin/hipcc $HIPFLAGS -c "$ROOT/octree-tracer_amd/csrc/svo_kernels.hip" -o "$OUT/svo_kernels.o"
-/opt/rocm/bin/hipcc $HIPFLAGS -c "$ROOT/octree-tracer_amd/csrc/svo_dual.hip" -o "$OUT/svo_dual.o"
 /opt/rocm/bin/hipcc $HIPFLAGS -c "$ROOT/octree-tracer_amd/csrc/svo_abi.cpp" -o "$OUT/svo_abi.o"
 /opt/rocm/bin/hipcc $HIPFLAGS -c "$ROOT/octree-tracer_amd/csrc/svo_comm.cpp" -o "$OUT/svo_comm.o"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o "$OUT/libsvo_hip.so" "$OUT/svo_kernels.o" "$OUT/svo_dual.o" "$OUT/svo_abi.o" "$OUT/svo_comm.o" "$OUT/svo_host.o" -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o "$OUT/libsvo_hip.so" "$OUT/svo_kernels.o" "$OUT/svo_abi.o" "$OUT/svo_comm.o" "$OUT/svo_host.o" -ldl
 gcc $SAN -std=c11 -ffp-contract=off -fno-fast-math -fPIC -pthread -shared -o "$OUT/libsvo_oracle.so" "$ROOT/oracle/svo_oracle.c" -lm -lpthread
 cd "$ROOT"
 LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)" \
