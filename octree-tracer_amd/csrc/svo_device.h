@@ -13,7 +13,8 @@ constexpr uint32_t kMaxDescent = 31;           // descent guard (see oracle/svo_
 constexpr int kTopLevels = 3;                  // K: octree levels folded into the LDS top table
 constexpr int kTopEntries = 1 << (3 * kTopLevels);
 constexpr int kTopAuxEntries = 8 + 64;  // level-1 and level-2 cells -> child group of the next level (kTopLevels = 3)
-constexpr int kPathBits = 24;                  // D: integer path-code bits per axis
+constexpr int kPathBits = 23;                  // D: path-code bits per axis (grid units: 2^(D-1) per unit of the reference's cube, so that
+                                               // 2^D + code is an exact f32 whose mantissa IS the code: DESIGN.md 4.2)
 constexpr int kCounterWords = 2048;            // 64 claim counters (8 lists x 8 counters), one per 128-byte line
 
 // Top-table entry (one per level-K cell, index = cx << 2K | cy << K | cz): level << 27 | child group index.

@@ -21,6 +21,26 @@
 #include "svo_device.h"
 #include "svo_trace_fn.h"
 
+// Step variants kept for same-box A/B builds (-DSVO_STEP_...=1); the defaults are what measured fastest.
+#ifndef SVO_STEP_CENTRE
+#define SVO_STEP_CENTRE 1
+#endif
+#ifndef SVO_STEP_MASK
+#define SVO_STEP_MASK 1
+#endif
+#ifndef SVO_STEP_BOUNDS
+#define SVO_STEP_BOUNDS 0
+#endif
+#ifndef SVO_WALK_STOP
+#define SVO_WALK_STOP 1
+#endif
+#ifndef SVO_TOP_IN_LDS   // 0: the top table is read from global memory (2 KiB less LDS per workgroup)
+#define SVO_TOP_IN_LDS 1
+#endif
+#ifndef SVO_WAVES_PER_SIMD   // of the default instantiation (static tree, trees up to depth 16)
+#define SVO_WAVES_PER_SIMD 7
+#endif
+
 namespace svo {
 
 
@@ -236,24 +256,57 @@ __global__ __launch_bounds__(256) void build_top_table_kernel(const uint32_t *no
 // Variant STACK (see file header).
 // ---------------------------------------------------------------------------------------------
 
-// The traversal runs in GRID UNITS: positions and directions are pre-multiplied by 2^23 (the path-code
+// The traversal runs in GRID UNITS: positions and directions are pre-multiplied by 2^(D-1) = 2^22 (the path-code
 // scale).  Scaling by a power of two commutes with every IEEE rounding involved (no overflow/underflow on
-// a clean ray), so  A = (C - P) + H,  t = A / Dr,  G = (P + Dr * t) +- K  are exactly 2^23 times the
-// reference's  a,  the same t,  and  2^23 * voxel_pos  -- and G is what the path codes need.
+// a clean ray), so  A = (C - P) + H,  t = A / Dr,  G = (P + Dr * t) +- K  are exactly 2^22 times the
+// reference's  a,  the same t,  and  2^22 * voxel_pos  -- and G is what the path codes need.
+//
+// Round 4: the step is written for the way gfx950 issues vector instructions (tools/issue_rate.hip, profiles/r04_issue_rate*.log):
+// plain f32 add / mul / fma (also with the clamp modifier) take 2 cycles of a SIMD and run BESIDE the other group -- compares,
+// selects, min/max, conversions, bit-field and shift-or forms, every three-operand integer instruction: 4 cycles each -- in which the
+// kernel of rounds 1-3 did five sixths of its work.  So everything the DDA step needs is now derived in f32, exactly:
+//   * a path code U (D = 23 bits) lives in a register as the bits of the float 2^23 + U, which IS 0x4B000000 | U: the walk
+//     extracts child bits from it, the step subtracts 2^23 and has U as a float;
+//   * the leaf centre is  floor(U / 2^s) 2^s + 2^(s-1) - 2^22  with the floor taken by the rounding of an addition:
+//     (U - (2^(s-1) - 1/2)) + 3 2^(22+s) lands on the multiple of 2^s below U + 1/2 (never a tie), all operands exact;
+//   * the tie mask  t_i == min  is  1 - clamp(clamp((t_i - min) 2^126) 2^24)  (a difference of two floats is 0 or at
+//     least 2^-149), the nudge  mask * copysign(k, dir)  one fma with it, the mask bits a sum of them;
+//   * in_bounds is a product of six clamps (a coordinate is a float: below 2^22 it is at most 2^22 - 1/4, so
+//     clamp(4 (2^22 - g)) is exactly 1 or 0), the step limit one more factor, and ONE compare decides who goes on;
+//   * steps, mask and lane state are floats; the state changes by multiplication (svo_trace_fn.h).
+// What stays in the other group: floor() of the three new coordinates, the xor / or3 / count-leading-zeros that finds the
+// restart level, one ldexp, min3, four compares -- 20 instead of 75 per round.
+// The kernel's first argument, re-read from the kernarg segment where it is needed: ray generation and the record writes use
+// some sixty scalar values (the uniforms, the work description, five pointers) that the hot loop never touches; read through
+// the by-value parameter they would be loaded once and stay in scalar registers for the whole kernel, which has none to spare --
+// the compiler then parks wave-uniform values and constants in VECTOR registers, which is what bounds the occupancy.  The empty
+// asm makes the pointer opaque, so the loads stay where they are written (scalar loads: the pointer is uniform).
+__device__ __forceinline__ const TraceArgs &fresh_args() {
+    auto p = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const TraceArgs *)p;
+}
+
 // CNT: hit counters live (adaptive mode, shader.wgsl:157-161), see step 3a in the loop.
 template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD>
-__global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
+__global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : SVO_WAVES_PER_SIMD)) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
     constexpr int SMAX = K + 1 + NS;   // last level kept on the LDS stack = deepest level resolved
     static_assert(SMAX <= D - 1, "stack deeper than the path codes");
     constexpr int TBL = 1 << (3 * K);
-    constexpr float kScale = 8388608.0f;  // 2^23
-    constexpr float kInvScale = 1.0f / 8388608.0f;
+    constexpr bool kTopInLds = SVO_TOP_IN_LDS != 0;
+    constexpr int TOFF = kTopInLds ? TBL : 0;  // LDS words in front of the ancestor stacks
+    static_assert(D == 23, "2^D + code must be an f32 with unit spacing");
+    constexpr float kScale = (float)(1 << (D - 1));  // 2^22: grid units per unit of the cube
+    constexpr float kInvScale = 1.0f / kScale;
+    constexpr float kMagic = (float)(1 << D);        // 2^23: as_uint(kMagic + U) = 0x4B000000 | U for an integer 0 <= U < 2^23
+    constexpr float kNudge = 0.000002f * kScale;     // |voxel_pos nudge| (shader.wgsl:235) in grid units (exact: a power-of-two multiple)
     // SHD: direction of every shadow ray, -normalize(sun_dir) (wave-uniform, kept in scalar registers)
     float shadow_d0 = 0.0f, shadow_d1 = 0.0f, shadow_d2 = 0.0f;
     float sDr0 = 1.0f, sDr1 = 1.0f, sDr2 = 1.0f, sY0 = 1.0f, sY1 = 1.0f, sY2 = 1.0f;  // what ray_enter and the pick-up make of it
+    float sS0 = 1.0f, sS1 = 1.0f, sS2 = 1.0f;
     if (SHD) {
         auto uni = [](float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); };
         float sun[3];
@@ -263,11 +316,12 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
         sDr1 = uni((shadow_d1 + ((shadow_d1 == 0.0f) ? 1.0f : 0.0f) * 0.000001f) * kScale);
         sDr2 = uni((shadow_d2 + ((shadow_d2 == 0.0f) ? 1.0f : 0.0f) * 0.000001f) * kScale);
         sY0 = uni(1.0f / sDr0); sY1 = uni(1.0f / sDr1); sY2 = uni(1.0f / sDr2);
+        sS0 = uni(copysign_bits(1.0f, sDr0)); sS1 = uni(copysign_bits(1.0f, sDr1)); sS2 = uni(copysign_bits(1.0f, sDr2));
     }
     extern __shared__ uint32_t lds[];
-    uint32_t *tbl = lds;                          // TBL entries
-    uint32_t *stk = lds + TBL;                    // [NS][BLOCK]
-    uint32_t *pool_all = stk + (NS + 1) * BLOCK;  // [BLOCK / 64][kPoolWords][64] (one spare stack row, see the descent)
+    const uint32_t *tbl = kTopInLds ? lds : a.top_table;  // TBL entries
+    uint32_t *stk = lds + TOFF;                   // [NS][BLOCK]
+    uint32_t *pool_all = stk + NS * BLOCK;  // [BLOCK / 64][kPoolWords][64]
     // CNT: level-1 / level-2 cell -> child group (kTopAuxEntries words behind the top table): read from global memory, where the
     // 288 bytes stay in the L1 -- in LDS they cost the sixth workgroup per CU (the allocation granule)
     const uint32_t *aux = a.top_table + TBL;
@@ -378,8 +432,10 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
         cq_n += (uint32_t)__popcll(m);
     };
 
-    for (uint32_t i = tid; i < (uint32_t)TBL; i += BLOCK) tbl[i] = a.top_table[i];
-    __syncthreads();
+    if (kTopInLds) {
+        for (uint32_t i = tid; i < (uint32_t)TBL; i += BLOCK) lds[i] = a.top_table[i];
+        __syncthreads();
+    }
 
     const uint32_t n_items = a.work.n_items;
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + tid) >> 6);
@@ -444,50 +500,65 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
     if (DBG) t_begin = __builtin_amdgcn_s_memrealtime();
 
     // per-lane ray state
-    uint32_t st = 0;                  // packed, see ST_*
+    float stf = ST_IDLE;              // see ST_* (svo_trace_fn.h); negative: a shadow ray (SHD)
     uint32_t out = 0;                 // bits 0..25 output index, 26..31 entry normal code
     float P0 = 0, P1 = 0, P2 = 0, Dr0 = 1, Dr1 = 1, Dr2 = 1, Y0 = 1, Y1 = 1, Y2 = 1;
-    float K0 = 0, K1 = 0, K2 = 0;     // copysign(2e-6 * 2^23, dir): the nudge along each axis
+    float S0 = 1, S1 = 1, S2 = 1;     // copysign(1, dir): r_sign of shader.wgsl:211
     float dist = 0.0f, tcur = 0.0f;
-    int32_t ix = 0, iy = 0, iz = 0;
-    uint32_t lvl = 1, nidx = 0;       // next level to read and the child group it lives in
+    float stepsf = 0.0f;              // steps taken (shader.wgsl:240), an integer 0 .. 101
+    float nmf = 7.0f;                 // axes NOT in the last step's mask: bit i = t_i differed from the minimum (7: no step taken yet)
+    uint32_t mu0 = __float_as_uint(kMagic), mu1 = mu0, mu2 = mu0;  // path codes, as the bits of kMagic + code
+    // sh: at a leaf, the bit of the path codes that selects the child at the leaf's level, D - L (the leaf's cell is 2^sh grid
+    // units wide); before a walk, one more than the bit of the first level to read.  nidx: the child group that level lives in.
+    uint32_t sh = 1, nidx = 0;
+    uint32_t sp = ((uint32_t)TOFF + threadIdx.x) * 4u;  // LDS slot (byte offset) one row BELOW the walk's next push
     uint32_t leaf_off = 0, leaf_w = 0;  // current leaf: byte offset of its word, and the word
+    auto sabs = [](float x) -> float { return SHD ? __builtin_fabsf(x) : x; };  // (only the SHD instantiation has negative states)
+    constexpr bool kWalkStops = SVO_WALK_STOP != 0 && !CNT;
     uint32_t satm = 0;                // CNT: bit l = the word of level l on the lane's current path is known to be saturated (step 3a)
 
     // (re)start a descent: from the LDS top table when the restart level r is at most K+1 (the table also
     // knows leaves that cover a whole level-K cell), else from the lane's ancestor stack.  One LDS read.
+    auto lds_at = [&](uint32_t byte_offset) -> uint32_t & { return *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + byte_offset); };
     auto restart_at = [&](uint32_t r) {
         const bool top = r <= (uint32_t)(K + 1);
-        const uint32_t addr = (uint32_t)TBL + (r - SBASE) * BLOCK + tid;
+        const uint32_t addr = ((uint32_t)TOFF + tid) * 4u + (r - SBASE) * (uint32_t)(BLOCK * 4);  // stack[r - SBASE][lane], in bytes
         if (__ballot(top)) {  // wave-uniform: most rounds no lane crosses a level-(K+1) boundary
-            const uint32_t cell = ((uint32_t)(ix >> (D - K)) << (2 * K)) | ((uint32_t)(iy >> (D - K)) << K) |
-                                  (uint32_t)(iz >> (D - K));
-            const uint32_t e = lds[top ? cell : addr];
-            lvl = top ? (e >> 27) : r;
+            const uint32_t cell = (__builtin_amdgcn_ubfe(mu0, D - K, K) << (2 * K)) | (__builtin_amdgcn_ubfe(mu1, D - K, K) << K) |
+                                  __builtin_amdgcn_ubfe(mu2, D - K, K);
+            const uint32_t e = kTopInLds ? lds_at(top ? cell * 4u : addr) : (top ? a.top_table[cell] : lds_at(addr));
+            sh = (uint32_t)(D + 1) - (top ? (e >> 27) : r);
             nidx = e & 0x07FFFFFFu;
+            // a walk from the table starts at level K+1 or above: its first push (if any) is the group of level K+2, row 0
+            sp = top ? ((uint32_t)TOFF + tid) * 4u - (uint32_t)(BLOCK * 4) : addr;
         } else {  // a stack entry is the child group itself (< 2^27): nothing to unpack
-            lvl = r;
-            nidx = lds[addr];
+            sh = (uint32_t)(D + 1) - r;
+            nidx = lds_at(addr);
+            sp = addr;  // (the walk's first push goes to the row of level r + 1)
         }
     };
 
     // write the record of a finished ray (deferred to the next refill so that it runs for many lanes at once)
     auto flush_record = [&](bool may_continue) {
+        const TraceArgs &a = fresh_args();  // (shadows the parameter: see fresh_args)
         // (the leaf word the ray ended on is still in the lane's register: an interior word = the walk gave up at level SMAX)
-        const bool too_deep = leaf_w < (kVoxelOffset << 4), solid = (leaf_w >> 4) != kVoxelOffset, inb = (st & ST_F_INB) != 0u;
+        const uint32_t steps = (uint32_t)stepsf;
+        // a ray that ends without stopping in its leaf left the cube -- its count is at most 100 -- or ran into the step limit,
+        // which is the one way to count 101 (shader.wgsl:237-244)
+        const bool too_deep = leaf_w < (kVoxelOffset << 4), solid = (leaf_w >> 4) != kVoxelOffset, inb = steps == 101u;
         const bool stop_here = too_deep || solid;
         if (too_deep) atomicOr(a.status, 1u);  // reported by svo_sync
-        const uint32_t L = (st >> ST_L_SHIFT) & 31u, nm = (st >> ST_M_SHIFT) & 7u;
+        const uint32_t L = (uint32_t)D - sh, nm = 7u - (uint32_t)nmf;
         uint32_t c0n = (Dr0 > 0.0f) ? 2u : 1u, c1n = (Dr1 > 0.0f) ? 2u : 1u, c2n = (Dr2 > 0.0f) ? 2u : 1u;
         uint32_t ncode = ((nm & 1u) ? c0n : 0u) | ((nm & 2u) ? (c1n << 2) : 0u) | ((nm & 4u) ? (c2n << 4) : 0u);
-        if (st & ST_ENTRY) ncode = out >> 26;             // no step taken: the entry normal
+        if (steps == 0u) ncode = out >> 26;               // no step taken: the entry normal
         if (!stop_here && !inb) ncode = 0u;               // left the cube: the miss record carries no normal
         const uint32_t leaf_index = leaf_off >> 2;
         const uint32_t value = too_deep ? 0xFF000000u : (solid ? leaf_index : (!inb ? 0x20202000u : 0xFF000000u));
         const uint32_t depth = (too_deep || (!solid && inb)) ? 100u : L;
         const uint32_t hit = (stop_here || inb) ? 1u : 0u;
-        const bool was_shadow = SHD && (st & ST_SHADOW) != 0u;
-        write_hit(was_shadow ? a.shadow_hits : a.hits, out & 0x03FFFFFFu, value, dist + tcur, st & 0xFFu, depth, hit, ncode);
+        const bool was_shadow = SHD && stf < 0.0f;
+        write_hit(was_shadow ? a.shadow_hits : a.hits, out & 0x03FFFFFFu, value, dist + tcur, steps, depth, hit, ncode);
         if (a.aux_t && !was_shadow) a.aux_t[out & 0x03FFFFFFu] = tcur;
         if (SHD && !was_shadow) {
             // fs_main's shadow ray (shader.wgsl:275-280), on the lane that found the hit: same arithmetic as
@@ -499,7 +570,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                 const float pw[3] = {P0 * kInvScale, P1 * kInvScale, P2 * kInvScale};
                 const float dw[3] = {Dr0 * kInvScale, Dr1 * kInvScale, Dr2 * kInvScale};
                 float org[3], nrm[3];
-                secondary_origin(pw, dw, st & 0xFFu, ncode, tcur, org, nrm);
+                secondary_origin(pw, dw, steps, ncode, tcur, org, nrm);
                 if (in_bounds(org[0], org[1], org[2])) {  // ray_enter's common case: the ray starts where it is
                     pos2[0] = org[0]; pos2[1] = org[1]; pos2[2] = org[2];
                     go = true;
@@ -514,43 +585,52 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                 }
             }
             if (go) {
-                const uint32_t L_old = (st >> ST_L_SHIFT) & 31u;
+                const uint32_t L_old = L;
                 P0 = pos2[0] * kScale; P1 = pos2[1] * kScale; P2 = pos2[2] * kScale;
                 Dr0 = sDr0; Dr1 = sDr1; Dr2 = sDr2;  // the same for every shadow ray
                 Y0 = sY0; Y1 = sY1; Y2 = sY2;
-                K0 = copysign_bits(0.000002f * 8388608.0f, Dr0);
-                K1 = copysign_bits(0.000002f * 8388608.0f, Dr1);
-                K2 = copysign_bits(0.000002f * 8388608.0f, Dr2);
+                S0 = sS0; S1 = sS1; S2 = sS2;
                 dist = d2;
                 tcur = 0.0f;
+                stepsf = 0.0f;
+                nmf = 7.0f;
                 const uint32_t ecode = normal_code(truncf(pos2[0] * 1.000001f)) | (normal_code(truncf(pos2[1] * 1.000001f)) << 2) |
                                        (normal_code(truncf(pos2[2] * 1.000001f)) << 4);
                 out = (out & 0x03FFFFFFu) | (ecode << 26);
-                const int32_t jx = entry_code<GE>(P0), jy = entry_code<GE>(P1), jz = entry_code<GE>(P2);
-                const uint32_t diff = (uint32_t)((ix ^ jx) | (iy ^ jy) | (iz ^ jz));
-                const uint32_t c = (uint32_t)__clz((int)((diff << 8) | 0x80u));  // levels the old and the new path share
-                ix = jx; iy = jy; iz = jz;
+                const uint32_t j0 = entry_magic<GE>(P0), j1 = entry_magic<GE>(P1), j2 = entry_magic<GE>(P2);
+                const uint32_t diff = (mu0 ^ j0) | (mu1 ^ j1) | (mu2 ^ j2);  // (the exponent bits cancel)
+                const uint32_t c = (uint32_t)__clz((int)((diff << (32 - D)) | (1u << (31 - D))));  // levels the old and the new path share
+                mu0 = j0; mu1 = j1; mu2 = j2;
                 const uint32_t r = max(min(min(c + 1u, L_old), (uint32_t)SMAX), 1u);
-                st = ST_ACTIVE | ST_DESC | ST_ENTRY | ST_SHADOW;
+                stf = -ST_DESC;
                 if (CNT) satm &= (1u << r) - 1u;
                 restart_at(r);
                 return;
             }
             reinterpret_cast<uint4 *>(a.shadow_hits)[out & 0x03FFFFFFu] = make_uint4(0u, 0u, 0u, 0u);  // no shadow ray: the record of a ray that never enters
         }
-        st = 0u;
+        stf = ST_IDLE;
     };
 
-    // the one-level walk: one dependent word per level below (lvl, nidx), ancestors pushed on the lane's LDS stack
+    // the one-level walk: one dependent word per level below (sh, nidx), ancestors pushed on the lane's LDS stack
     auto descend = [&]() {
             uint32_t off, w, key;
-            uint32_t sh = (uint32_t)D - lvl + 1u;            // (bit of the path codes that selects the child) + 1
-            // slot of level lvl + 1; a descent that starts on a leaf above level K+1 (from the top table) pushes its
-            // one dead word into row 0, which is rewritten before any restart can read it
-            uint32_t sp = (uint32_t)TBL + (max(lvl, (uint32_t)(SBASE - 1)) - (uint32_t)(SBASE - 1)) * BLOCK + tid;
-            // The loop is rotated: a word is read, then looked at -- a leaf, or level SMAX, ends the walk BEFORE anything is pushed for
-            // it (the push of the exiting iteration landed below the leaf, where no restart reads: one LDS store per walk for nothing)
-            auto step_down = [&]() {
+            // sh -= 1, then the child the position selects at the level of that bit: x << 2 | y << 1 | z.  Three-operand forms the
+            // compiler does not pick by itself, in ONE asm statement (the compiler pads every inline-asm statement with an s_nop, and
+            // keeping the decrement inside saves a copy of the counter)
+            auto child_below = [&]() -> uint32_t {
+                uint32_t c, tmp;
+                asm("v_add_u32 %2, -1, %2\n\t"
+                    "v_bfe_u32 %0, %3, %2, 1\n\t"
+                    "v_bfe_u32 %1, %4, %2, 1\n\t"
+                    "v_lshl_or_b32 %0, %0, 1, %1\n\t"
+                    "v_bfe_u32 %1, %5, %2, 1\n\t"
+                    "v_lshl_or_b32 %0, %0, 1, %1"
+                    : "=&v"(c), "=&v"(tmp), "+v"(sh)
+                    : "v"(mu0), "v"(mu1), "v"(mu2));
+                return c;
+            };
+            auto tally = [&]() {
                 if (DBG) {
                     const uint64_t in_loop = __ballot(true);
                     if (lane == (uint32_t)__ffsll((unsigned long long)in_loop) - 1u) {  // (tallies summed over lanes at the end)
@@ -558,35 +638,34 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                         if (!CNT) dbg_desc_lanes += (uint32_t)__popcll(in_loop);
                     }
                 }
-                // sh -= 1 (level being read: D - sh); child = x << 2 | y << 1 | z; byte offset = (nidx + child) << 2.
-                // Three-operand forms the compiler does not pick by itself, in ONE asm statement (the compiler pads every
-                // inline-asm statement with an s_nop, and keeping the decrement inside saves a copy of the counter)
-                uint32_t tmp;
-                asm("v_add_u32 %2, -1, %2\n\t"
-                    "v_bfe_u32 %0, %3, %2, 1\n\t"
-                    "v_bfe_u32 %1, %4, %2, 1\n\t"
-                    "v_lshl_or_b32 %0, %0, 1, %1\n\t"
-                    "v_bfe_u32 %1, %5, %2, 1\n\t"
-                    "v_lshl_or_b32 %0, %0, 1, %1\n\t"
-                    "v_add_lshl_u32 %0, %6, %0, 2"
-                    : "=&v"(off), "=&v"(tmp), "+v"(sh)
-                    : "v"(ix), "v"(iy), "v"(iz), "v"(nidx));
+            };
+            // The loop is rotated twice.  (1) A word is read, then looked at: a leaf, or level SMAX, ends the walk BEFORE anything is
+            // pushed for it.  (2) While a word travels the child index of the NEXT level is worked out -- it depends on the position
+            // only -- so that between a word's arrival and the next load stand a shift and an add instead of eight instructions.
+            uint32_t c = child_below();
+            auto read_word = [&]() {
+                tally();
+                off = (nidx + c) << 2;
                 w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
                 if (CNT) satm |= ((w & 15u) == 15u ? 1u : 0u) << ((uint32_t)D - sh);  // (a counter never goes down within a frame)
+                c = child_below();  // (sh now points one level below the word in flight)
                 // sign bit: a leaf (word >= VOXEL_OFFSET << 4), or level SMAX reached (deeper trees are refused)
-                key = w | (sh - (uint32_t)(D - SMAX + 1));
+                key = w | (sh - (uint32_t)(D - SMAX));
             };
-            step_down();
+            read_word();
             while ((int32_t)key >= 0) {
                 nidx = w >> 4;
-                lds[sp] = nidx;
-                sp += BLOCK;
-                step_down();
+                sp += (uint32_t)(BLOCK * 4);
+                lds_at(sp) = nidx;
+                read_word();
             }
-            lvl = (uint32_t)D - sh;
+            sh += 1u;  // back to the leaf's own bit
             leaf_off = off;
             leaf_w = w;
-            st = (st & ~(ST_L_MASK | ST_DESC)) | (lvl << ST_L_SHIFT);
+            // ST_DESC -> ST_LEAF; or straight to ST_PENDING when the ray ends in this leaf (anything but an empty leaf: a solid one, or
+            // an interior word at level SMAX) -- with live hit counters the step section has to see the lane once more (step 3a)
+            if (kWalkStops) stf *= ((w >> 4) != kVoxelOffset) ? 0.25f : 0.5f;
+            else stf *= 0.5f;
             };
 
     // Camera shortcut.  Every primary ray of a camera that stands INSIDE the cube starts at the same point, hence in the
@@ -603,20 +682,20 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
     if (CAM && a.cam_shortcut && a.work.mode != 2) {
         const RayIn r0 = gen_ray(a.u, 0u, 0u);  // (the position does not depend on the pixel)
         if (in_bounds(r0.px, r0.py, r0.pz)) {   // ray_enter: such rays start where they are, dist = 0
-            ix = entry_code<GE>(r0.px * kScale);
-            iy = entry_code<GE>(r0.py * kScale);
-            iz = entry_code<GE>(r0.pz * kScale);
-            st = ST_ACTIVE | ST_DESC;
+            mu0 = entry_magic<GE>(r0.px * kScale);
+            mu1 = entry_magic<GE>(r0.py * kScale);
+            mu2 = entry_magic<GE>(r0.pz * kScale);
+            stf = ST_DESC;
             restart_at(1u);
             descend();
-            uint32_t v = lane < (uint32_t)NS ? lds[(uint32_t)TBL + lane * BLOCK + tid] : 0u;  // row `lane` of this lane's own column
+            uint32_t v = lane < (uint32_t)NS ? lds[(uint32_t)TOFF + lane * BLOCK + tid] : 0u;  // row `lane` of this lane's own column
             v = lane == (uint32_t)NS ? leaf_off : v;
             v = lane == (uint32_t)NS + 1u ? leaf_w : v;
-            v = lane == (uint32_t)NS + 2u ? lvl : v;
+            v = lane == (uint32_t)NS + 2u ? sh : v;  // (D - the leaf's level)
             camv = v;
             // worth it when the camera's leaf is deep (the copy at pick-up costs about two walk iterations)
-            cam_ok = (uint32_t)__builtin_amdgcn_readfirstlane(lvl) >= (uint32_t)(SBASE + 2);
-            st = 0u;
+            cam_ok = (uint32_t)D - (uint32_t)__builtin_amdgcn_readfirstlane(sh) >= (uint32_t)(SBASE + 2);
+            stf = ST_IDLE;
         }
     }
 
@@ -624,12 +703,12 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
         if (DBG) c_mark = __builtin_amdgcn_s_memtime();
         if (DBG) {  // per-wave timeline build only (SVO_OPT_DEBUG_BUFFER): the default instantiation carries none of this
             n_rounds += 1;
-            const uint32_t nd = (uint32_t)__popcll(__ballot(st >= (ST_ACTIVE | ST_DESC)));
+            const uint32_t nd = (uint32_t)__popcll(__ballot(sabs(stf) == ST_DESC));
             (void)nd;
             if (!CNT) dbg_desc_rounds += nd ? 1u : 0u;
         }
         // ---- 1. descent: one dependent word per level below the restart level ----
-        if (st >= (ST_ACTIVE | ST_DESC)) {  // DESC implies ACTIVE: one unsigned compare
+        if (sabs(stf) == ST_DESC) {
             descend();
         }
         if (DBG) {
@@ -644,13 +723,13 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
         // here descend in the next round.)
         // Common case first and cheap: fewer than refill_min idle lanes -> straight on.  (refill_min <= 64, so a wave
         // without active lanes always takes the slow path, where the exit test lives.)
-        uint64_t act = __ballot((int32_t)st < 0);  // ST_ACTIVE is the sign bit: one compare
+        uint64_t act = __ballot(sabs(stf) >= ST_LEAF);  // lanes with a ray in flight
         const uint32_t n_idle = 64u - (uint32_t)__popcll(act);
         if (n_idle >= a.refill_min) {
             if (next == 0xFFFFFFFEu && pool_n == 0u) {  // now the answer of the early claim is needed
                 const uint64_t c_w0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
-                uint32_t sh = home / kSubs;
-                uint32_t s = entry_of(sh, __builtin_amdgcn_readfirstlane(pend) * kSubs + home % kSubs + ((gridDim.x + kShards - 1u - sh) / kShards) * (uint32_t)(BLOCK / 64));
+                uint32_t lst = home / kSubs;
+                uint32_t s = entry_of(lst, __builtin_amdgcn_readfirstlane(pend) * kSubs + home % kSubs + ((gridDim.x + kShards - 1u - lst) / kShards) * (uint32_t)(BLOCK / 64));
                 // The home counter ran out: lane i looks at counter i -- one load for all 64 -- and the wave draws from the first
                 // counter that still has entries, starting behind its own (the other counters of its list, then list by list), and
                 // makes that counter its home: later claims from it are issued ahead of time again (frames whose lists differ
@@ -672,10 +751,10 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                     if (!has) break;
                     const uint64_t rot = home ? ((has >> home) | (has << (64u - home))) : has;
                     home = (home + (uint32_t)__ffsll((unsigned long long)rot) - 1u) & 63u;
-                    sh = home / kSubs;
+                    lst = home / kSubs;
                     uint32_t k = 0u;
                     if (lane == 0) k = atomicAdd(work_counter + home * kShardStride, 1u);
-                    s = entry_of(sh, __builtin_amdgcn_readfirstlane(k) * kSubs + home % kSubs + ((gridDim.x + kShards - 1u - sh) / kShards) * (uint32_t)(BLOCK / 64));
+                    s = entry_of(lst, __builtin_amdgcn_readfirstlane(k) * kSubs + home % kSubs + ((gridDim.x + kShards - 1u - lst) / kShards) * (uint32_t)(BLOCK / 64));
                 }
                 // the next claim goes to the list's next counter: every wave of a list draws from all of its counters in turn, so
                 // the counters advance together and the list is consumed front to back, as with one counter (waves tied to one
@@ -695,6 +774,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                     if (DBG) dbg_gens += 1;
                     const uint64_t c_g0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
                     // -- generate the next (up to) 64 rays, all lanes --
+                    const TraceArgs &a = fresh_args();  // (shadows the parameter: see fresh_args)
                     const uint32_t q = next + lane;
                     bool alive = false;
                     float gp0 = 0, gp1 = 0, gp2 = 0, gd0 = 1, gd1 = 1, gd2 = 1, gdist = 0;
@@ -743,11 +823,8 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                         pool[3 * 64 + slot] = __float_as_uint(gd0);
                         pool[4 * 64 + slot] = __float_as_uint(gd1);
                         pool[5 * 64 + slot] = __float_as_uint(gd2);
-                        pool[6 * 64 + slot] = __float_as_uint(1.0f / gd0);  // RN(1 / Dr) = 2^-23 * RN(1 / dir)
-                        pool[7 * 64 + slot] = __float_as_uint(1.0f / gd1);
-                        pool[8 * 64 + slot] = __float_as_uint(1.0f / gd2);
-                        pool[9 * 64 + slot] = __float_as_uint(gdist);
-                        pool[10 * 64 + slot] = gout;
+                        pool[6 * 64 + slot] = __float_as_uint(gdist);
+                        pool[7 * 64 + slot] = gout;
                     }
                     pool_n = (uint32_t)__popcll(am);
                     pool_i = 0u;
@@ -760,9 +837,9 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                     if (DBG) c_gen += (uint32_t)(__builtin_amdgcn_s_memtime() - c_g0);
                 }
                 // -- idle lanes first write the record of the ray they finished, then take rays pool_i .. --
-                if (st & ST_PENDING) flush_record(true);
-                if (SHD) act = __ballot((int32_t)st < 0);  // lanes that went on with a shadow ray are not idle
-                if (!(st & ST_ACTIVE)) {
+                if (sabs(stf) == ST_PENDING) flush_record(true);
+                if (SHD) act = __ballot(sabs(stf) >= ST_LEAF);  // lanes that went on with a shadow ray are not idle
+                if (!(sabs(stf) >= ST_LEAF)) {
                     const uint64_t idle = ~act;
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
@@ -774,30 +851,32 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                         Dr0 = __uint_as_float(pool[3 * 64 + e]);
                         Dr1 = __uint_as_float(pool[4 * 64 + e]);
                         Dr2 = __uint_as_float(pool[5 * 64 + e]);
-                        Y0 = __uint_as_float(pool[6 * 64 + e]);
-                        Y1 = __uint_as_float(pool[7 * 64 + e]);
-                        Y2 = __uint_as_float(pool[8 * 64 + e]);
-                        K0 = copysign_bits(0.000002f * 8388608.0f, Dr0);
-                        K1 = copysign_bits(0.000002f * 8388608.0f, Dr1);
-                        K2 = copysign_bits(0.000002f * 8388608.0f, Dr2);
-                        dist = __uint_as_float(pool[9 * 64 + e]);
-                        out = pool[10 * 64 + e];
+                        Y0 = 1.0f / Dr0;  // RN(1 / Dr): what div_by_recip wants (three IEEE divisions per pick-up instead of three
+                        Y1 = 1.0f / Dr1;  // more words per pooled ray: 8 words keep a workgroup at 22 KiB of LDS)
+                        Y2 = 1.0f / Dr2;
+                        S0 = copysign_bits(1.0f, Dr0);
+                        S1 = copysign_bits(1.0f, Dr1);
+                        S2 = copysign_bits(1.0f, Dr2);
+                        dist = __uint_as_float(pool[6 * 64 + e]);
+                        out = pool[7 * 64 + e];
                         // entry path codes (the position may sit a rounding error outside the cube: clamp)
-                        ix = entry_code<GE>(P0);
-                        iy = entry_code<GE>(P1);
-                        iz = entry_code<GE>(P2);
+                        mu0 = entry_magic<GE>(P0);
+                        mu1 = entry_magic<GE>(P1);
+                        mu2 = entry_magic<GE>(P2);
                         tcur = 0.0f;
+                        stepsf = 0.0f;
+                        nmf = 7.0f;
                         if (CAM && cam_ok && dist == 0.0f) {
                             // a ray from the camera's own position: the walk the wave made at the start (see above)
-                            const uint32_t L0 = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 2);
+                            const uint32_t sh0 = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 2), L0 = (uint32_t)D - sh0;
                             for (uint32_t l = 0; l < (uint32_t)NS && l + (uint32_t)SBASE <= L0; l++)
-                                lds[(uint32_t)TBL + l * BLOCK + tid] = (uint32_t)__builtin_amdgcn_readlane((int)camv, (int)l);
+                                lds[(uint32_t)TOFF + l * BLOCK + tid] = (uint32_t)__builtin_amdgcn_readlane((int)camv, (int)l);
                             leaf_off = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS);
                             leaf_w = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 1);
-                            lvl = L0;
-                            st = ST_ACTIVE | ST_ENTRY | (L0 << ST_L_SHIFT);  // steps = 0, at its leaf
+                            sh = sh0;
+                            stf = (kWalkStops && (leaf_w >> 4) != kVoxelOffset) ? ST_PENDING : ST_LEAF;  // at its leaf, no step taken
                         } else {
-                            st = ST_ACTIVE | ST_DESC | ST_ENTRY;  // steps = 0, L = 0
+                            stf = ST_DESC;
                             if (CNT) satm = 0u;
                             restart_at(1u);
                         }
@@ -806,11 +885,11 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                 const uint32_t took = min(SHD ? 64u - (uint32_t)__popcll(act) : n_idle, pool_n);
                 pool_i += took;
                 pool_n -= took;
-                act = __ballot((int32_t)st < 0);
+                act = __ballot(sabs(stf) >= ST_LEAF);
             }
             if (SHD && !more) {  // nothing left to hand out, but finished primary rays still have their shadow rays to trace
-                if (st & ST_PENDING) flush_record(true);
-                act = __ballot((int32_t)st < 0);
+                if (sabs(stf) == ST_PENDING) flush_record(true);
+                act = __ballot(sabs(stf) >= ST_LEAF);
             }
             // the only exit: nothing in flight, nothing pooled, nothing left to claim.  (No lane active but work left --
             // e.g. a strip whose rays all miss the cube: the traversal below is skipped lane-wise and the loop comes back.)
@@ -818,7 +897,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
         }
 
         if (DBG) {
-            dbg_active += (uint32_t)__popcll(__ballot((st ^ ST_DESC) >= (ST_ACTIVE | ST_DESC)));
+            dbg_active += (uint32_t)__popcll(__ballot(sabs(stf) == ST_LEAF));
             const uint64_t now = __builtin_amdgcn_s_memtime();
             c_refill += (uint32_t)(now - c_mark);
             c_mark = now;
@@ -835,14 +914,14 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
             // table stands for them), are reported until the table knows them -- a compare-and-swap that finds a 15 does nothing.
             // Final counters = min(15, old + visits), like the RESTART kernel.
             // (Wave-uniform control flow around per-lane predicates: the queue cursor is a scalar.)
-            const bool at_leaf = (st ^ ST_DESC) >= (ST_ACTIVE | ST_DESC);
+            const bool at_leaf = sabs(stf) == ST_LEAF;
             const uint64_t c_c0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
             if (__ballot(at_leaf) != 0ull) {
-                const uint32_t L = (st >> ST_L_SHIFT) & 31u;
+                const uint32_t L = (uint32_t)D - sh;
                 uint32_t todo = at_leaf ? (~satm & ((1u << L) - 2u)) : 0u;  // levels 1 .. L-1 not known to be saturated
                 constexpr uint32_t kTopLv = (2u << K) - 2u;  // levels 1 .. K
                 auto cell_k = [&]() -> uint32_t {
-                    return (((uint32_t)ix >> (D - K)) << (2 * K)) | (((uint32_t)iy >> (D - K)) << K) | ((uint32_t)iz >> (D - K));
+                    return (__builtin_amdgcn_ubfe(mu0, D - K, K) << (2 * K)) | (__builtin_amdgcn_ubfe(mu1, D - K, K) << K) | __builtin_amdgcn_ubfe(mu2, D - K, K);
                 };
                 if (__ballot((todo & kTopLv) != 0u) != 0ull) {  // (rays picked up, rays that crossed a top-level boundary)
                     const uint32_t cellK = cell_k();
@@ -861,14 +940,14 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
                     const uint32_t kk = l - 1u, shc = (uint32_t)D - kk;
                     uint32_t g = 0u;
                     if (l >= (uint32_t)SBASE) {
-                        g = lds[(uint32_t)TBL + (l - (uint32_t)SBASE) * BLOCK + tid];
+                        g = lds[(uint32_t)TOFF + (l - (uint32_t)SBASE) * BLOCK + tid];
                     } else if (l >= 2u) {
-                        const uint32_t cell = (((uint32_t)ix >> shc) << (2u * kk)) | (((uint32_t)iy >> shc) << kk) | ((uint32_t)iz >> shc);
+                        const uint32_t cell = (__builtin_amdgcn_ubfe(mu0, shc, kk) << (2u * kk)) | (__builtin_amdgcn_ubfe(mu1, shc, kk) << kk) | __builtin_amdgcn_ubfe(mu2, shc, kk);
                         g = kk == (uint32_t)K ? (tbl[cell] & 0x07FFFFFFu) : aux[(kk == 1u ? 0u : 8u) + cell];
                     }
-                    const uint32_t bit = (uint32_t)D - l;  // (l = 0: bit 24 of a 24-bit code, i.e. 0 -- and p is replaced below)
-                    uint32_t p = g + ((__builtin_amdgcn_ubfe((uint32_t)ix, bit, 1u) << 2) | (__builtin_amdgcn_ubfe((uint32_t)iy, bit, 1u) << 1) |
-                                      __builtin_amdgcn_ubfe((uint32_t)iz, bit, 1u));
+                    const uint32_t bit = (uint32_t)D - l;  // (l = 0: bit D, which belongs to the exponent of kMagic -- and p is replaced below)
+                    uint32_t p = g + ((__builtin_amdgcn_ubfe(mu0, bit, 1u) << 2) | (__builtin_amdgcn_ubfe(mu1, bit, 1u) << 1) |
+                                      __builtin_amdgcn_ubfe(mu2, bit, 1u));
                     p = l == 0u ? leaf_off >> 2 : p;
                     if (mine && sat_tags[sat_slot(p)] == p) {  // some lane of the workgroup has seen it reach 15
                         satm |= (1u << l) & ~1u;
@@ -883,79 +962,95 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
             }
             if (DBG) dbg_desc_start += (uint32_t)(__builtin_amdgcn_s_memtime() - c_c0);  // (CNT: slot 15 = cycles spent counting)
         }
-        // ---- 3. hit test / DDA step (shader.wgsl:215-244), clean rays, grid units ----
-        if ((st ^ ST_DESC) >= (ST_ACTIVE | ST_DESC)) {  // ST_ACTIVE and not ST_DESC: at a leaf (rays picked up above descend first)
-            const uint32_t L = (st >> ST_L_SHIFT) & 31u;
-            const bool too_deep = leaf_w < (kVoxelOffset << 4);  // descent stopped on an interior word
-            const bool solid = (leaf_w >> 4) != kVoxelOffset;
-            // leaf centre in grid units straight from the path code: keep the top L bits, set the next one
-            const uint32_t sh = (uint32_t)D - L;
-            const uint32_t keep = 0xFFFFFFFFu << sh, halfbit = 1u << (sh - 1u);
-            const float C0 = (float)((int32_t)(((uint32_t)ix & keep) | halfbit) - 8388608);
-            const float C1 = (float)((int32_t)(((uint32_t)iy & keep) | halfbit) - 8388608);
-            const float C2 = (float)((int32_t)(((uint32_t)iz & keep) | halfbit) - 8388608);
-            const float Hm = __uint_as_float((150u - L) << 23);  // 2^(23-L) = 2^23 * voxel_size / 2
-            // r_sign * voxel_size / 2 = copysign(2^-L, dir): dir is never 0 or NaN on a clean ray
-            const float t0 = div_by_recip((C0 - P0) + copysign_bits(Hm, Dr0), Dr0, Y0);
-            const float t1 = div_by_recip((C1 - P1) + copysign_bits(Hm, Dr1), Dr1, Y1);
-            const float t2 = div_by_recip((C2 - P2) + copysign_bits(Hm, Dr2), Dr2, Y2);
-            // no NaNs here, so IEEE minNum equals the oracle's (b < a) ? b : a up to the sign of a zero,
-            // which no later value depends on
-            // (no NaNs, so "t_i <= min(t_j, t_k)" is "t_i equals the minimum of the three")
-            const float tnew = __builtin_fminf(__builtin_fminf(t0, t1), t2);
-            const bool m0 = t0 == tnew, m1 = t1 == tnew, m2 = t2 == tnew;
-            // voxel_pos = pos + dir * t - normal * 2e-6, normal = mask * -sign(dir): subtracting -k is adding k
-            float G0 = P0 + Dr0 * tnew, G1 = P1 + Dr1 * tnew, G2 = P2 + Dr2 * tnew;
-            G0 = m0 ? G0 + K0 : G0;
-            G1 = m1 ? G1 + K1 : G1;
-            G2 = m2 ? G2 + K2 : G2;
-            const bool inb = (__builtin_fmaxf(__builtin_fmaxf(G0, G1), G2) < kScale) &&
-                             (__builtin_fminf(__builtin_fminf(G0, G1), G2) >= -kScale);
-            const bool stop_here = too_deep || solid;         // finish before stepping
-            const uint32_t mbits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u);
-            // A ray ends here when its leaf is solid (or the walk gave up), when the step leaves the cube, or when the count after
-            // this step exceeds 100 (iff it is 100 now).  Some lane of a wave ends its ray in nine rounds of ten, so nothing of
-            // that sits in a branch of its own (round 3: the branch ran ~25 instructions for two lanes): the state of a ray that
-            // goes on and of one that ends differ by selects, and what the record needs beyond that -- solid / gave up -- is
-            // read off the leaf word when the record is written (flush_record).
-            const bool end = stop_here || !inb || (st & 0xFFu) >= 100u;
-            // the step is taken unless the ray stops in this leaf (its normal, distance and -- if it stays inside -- count are
-            // what the record shows)
-            tcur = stop_here ? tcur : tnew;
-            const uint32_t st_step = ((st & ~(ST_M_MASK | ST_ENTRY)) | (mbits << ST_M_SHIFT)) + (inb ? 1u : 0u);
-            st = stop_here ? st : st_step;
-            const uint32_t st_end = (st & ~(ST_ACTIVE | ST_DESC)) | ST_PENDING | (inb ? ST_F_INB : 0u);
-            st = end ? st_end : st;
-            if (!end) {
-                // new path codes: the position is inside the cube, so no clamping of G
-                int32_t jx, jy, jz;
-                if (GE) {
-                    jx = cvt_floor_i32(G0) + 8388608;
-                    jy = cvt_floor_i32(G1) + 8388608;
-                    jz = cvt_floor_i32(G2) + 8388608;
-                } else {
-                    // ceil(G) - 1 + 2^23 clamped at 0, with ceil(G) = -floor(-G): the clamp only acts on the face G = -2^23
-                    int32_t f0, f1, f2;  // floor(-G): one asm statement for the three conversions (see the descent)
-                    asm("v_cvt_flr_i32_f32_e64 %0, -%3\n\t"
-                        "v_cvt_flr_i32_f32_e64 %1, -%4\n\t"
-                        "v_cvt_flr_i32_f32_e64 %2, -%5"
-                        : "=&v"(f0), "=&v"(f1), "=&v"(f2)
-                        : "v"(G0), "v"(G1), "v"(G2));
-                    jx = 8388607 - min(f0, 8388607);
-                    jy = 8388607 - min(f1, 8388607);
-                    jz = 8388607 - min(f2, 8388607);
+        // ---- 3. hit test / DDA step (shader.wgsl:215-244), clean rays, grid units; see the header of this kernel ----
+        if (sabs(stf) == ST_LEAF) {  // at a leaf (rays picked up above descend first)
+            // (leaf words 0x8000000c, c the counter bits, are the empty leaves: everything else ends the ray here -- a solid
+            // leaf, or an interior word at level SMAX -- with the normal, distance and count the last step left)
+            if (!kWalkStops && (leaf_w >> 4) != kVoxelOffset) {
+                stf *= 0.5f;  // ST_LEAF -> ST_PENDING
+            } else {
+                const float Hm = __builtin_amdgcn_ldexpf(0.5f, (int)sh);     // 2^(sh-1) = voxel_size / 2 in grid units (sh = D - L >= 1)
+                const float hmh = Hm - 0.5f, hbig = Hm * 25165824.0f, hc = Hm - kScale;  // (3 * 2^23 * Hm = 1.5 * 2^(23+sh): ulp 2^sh)
+                // leaf centre along one axis and a = (centre - pos) + r_sign * voxel_size / 2 (shader.wgsl:229): U - (h - 1/2) is exact
+                // and never halfway between two multiples of 2^sh, so adding and subtracting hbig rounds it to the leaf's lower
+                // corner floor(U / 2^sh) 2^sh; + (h - 2^22) makes that the centre, exactly (the reference sums +-2^-k: exact too)
+#if SVO_STEP_CENTRE == 1
+                // (variant: the lower corner by masking the code's low bits -- one and-or of the other instruction group per axis)
+                const uint32_t keepm = 0xFFFFFFFFu << sh, hbit = __float_as_uint(kMagic + Hm);
+                auto t_axis = [&](uint32_t mu, float P, float Dr, float Y, float S) -> float {
+                    const float c = __uint_as_float((mu & keepm) | hbit) - (kMagic + kScale);
+                    return div_by_recip(__builtin_fmaf(S, Hm, c - P), Dr, Y);
+                };
+                (void)hmh; (void)hbig; (void)hc;
+#else
+                auto t_axis = [&](uint32_t mu, float P, float Dr, float Y, float S) -> float {
+                    const float g = (__uint_as_float(mu) - kMagic) - hmh;
+                    const float c = ((g + hbig) - hbig) + hc;
+                    return div_by_recip(__builtin_fmaf(S, Hm, c - P), Dr, Y);
+                };
+#endif
+                const float t0 = t_axis(mu0, P0, Dr0, Y0, S0), t1 = t_axis(mu1, P1, Dr1, Y1, S1), t2 = t_axis(mu2, P2, Dr2, Y2, S2);
+                // no NaNs here, so IEEE minNum equals the oracle's (b < a) ? b : a up to the sign of a zero, which no later value
+                // depends on, and "t_i <= min(t_j, t_k)" is "t_i equals the minimum of the three"
+                const float tnew = __builtin_fminf(__builtin_fminf(t0, t1), t2);
+                // f_i = 0 where t_i is that minimum, else 1: the difference is 0 or at least 2^-149, and 2^126 * 2^24 saturates it
+                auto differs = [&](float t) -> float {
+                    const float e = __builtin_amdgcn_fmed3f((t - tnew) * 8.5070592e37f, 0.0f, 1.0f);  // (clamp modifier; 2^126)
+                    return __builtin_amdgcn_fmed3f(e * 16777216.0f, 0.0f, 1.0f);
+                };
+#if SVO_STEP_MASK == 1
+                const float f0 = t0 == tnew ? 0.0f : 1.0f, f1 = t1 == tnew ? 0.0f : 1.0f, f2 = t2 == tnew ? 0.0f : 1.0f;
+                (void)differs;
+#else
+                const float f0 = differs(t0), f1 = differs(t1), f2 = differs(t2);
+#endif
+                // voxel_pos = pos + dir * t - normal * 2e-6, normal = mask * -sign(dir): k or 0, times the sign, in one fma
+                const float G0 = __builtin_fmaf(__builtin_fmaf(-kNudge, f0, kNudge), S0, P0 + Dr0 * tnew);
+                const float G1 = __builtin_fmaf(__builtin_fmaf(-kNudge, f1, kNudge), S1, P1 + Dr1 * tnew);
+                const float G2 = __builtin_fmaf(__builtin_fmaf(-kNudge, f2, kNudge), S2, P2 + Dr2 * tnew);
+                // in_bounds (shader.wgsl:177-180), -2^22 <= G < 2^22: G is a float, so below the bound it is at most 2^22 - 1/4 and
+                // 4 (2^22 - G) >= 1, at or above it <= 0; likewise 2 G + (2^23 + 1) >= 1 from -2^22 up and <= 0 from -2^22 - 1/2 down
+                auto inside = [&](float G) -> float {
+                    return __builtin_amdgcn_fmed3f(__builtin_fmaf(G, -4.0f, 4.0f * kScale), 0.0f, 1.0f) *
+                           __builtin_amdgcn_fmed3f(__builtin_fmaf(G, 2.0f, 2.0f * kScale + 1.0f), 0.0f, 1.0f);
+                };
+#if SVO_STEP_BOUNDS == 1
+                const float inbf = inside(__builtin_fmaxf(__builtin_fmaxf(G0, G1), G2)) * inside(__builtin_fminf(__builtin_fminf(G0, G1), G2));
+#else
+                const float inbf = (inside(G0) * inside(G1)) * inside(G2);
+#endif
+                // the ray goes on unless the step leaves the cube or the count after it exceeds 100 (iff it is 100 now)
+                const float contf = inbf * __builtin_amdgcn_fmed3f(100.0f - stepsf, 0.0f, 1.0f);
+                tcur = tnew;
+                stepsf += inbf;                                          // (shader.wgsl:237-240: counted only inside the cube)
+                nmf = __builtin_fmaf(f2, 4.0f, __builtin_fmaf(f1, 2.0f, f0));
+                stf *= __builtin_fmaf(contf, 1.5f, 0.5f);                // ST_LEAF -> ST_DESC (goes on) or ST_PENDING (ended)
+                if (contf > 0.5f) {
+                    // new path codes: the position is inside the cube.  `>` mode: ceil(G) - 1 + 2^22 = (2^22 - 1) - floor(-G), which
+                    // is -1 on the face G = -2^22: scaled by 2^-23 the code lies in [0, 1) and the clamp does that for nothing
+                    uint32_t n0, n1, n2;
+                    if (GE) {
+                        n0 = __float_as_uint(__builtin_floorf(G0) + (kScale + kMagic));
+                        n1 = __float_as_uint(__builtin_floorf(G1) + (kScale + kMagic));
+                        n2 = __float_as_uint(__builtin_floorf(G2) + (kScale + kMagic));
+                    } else {
+                        auto code_gt = [&](float G) -> uint32_t {
+                            const float us = __builtin_amdgcn_fmed3f(__builtin_fmaf(__builtin_floorf(-G), -1.0f / kMagic, (kScale - 1.0f) / kMagic), 0.0f, 1.0f);
+                            return __float_as_uint(__builtin_fmaf(us, kMagic, kMagic));
+                        };
+                        n0 = code_gt(G0); n1 = code_gt(G1); n2 = code_gt(G2);
+                    }
+                    // first level at which the old and the new path differ (the exponent bits cancel in the xor); the leaf's own
+                    // bit is or-ed in, so that level is at most L -- also when nothing differs (the walk stops at L <= SMAX)
+                    const uint32_t lbit = __float_as_uint(__builtin_fmaf(Hm, 2.0f, kMagic)) & ((1u << D) - 1u);  // 1 << sh
+                    const uint32_t diff = ((mu0 ^ n0) | (mu1 ^ n1) | (mu2 ^ n2)) | lbit;
+                    mu0 = n0; mu1 = n1; mu2 = n2;
+                    const uint32_t r = (uint32_t)__builtin_clz(diff) - (uint32_t)(31 - D);  // (diff != 0)
+                    if (CNT) {  // levels r and below belong to a new path
+                        satm &= (1u << r) - 1u;
+                    }
+                    restart_at(r);
                 }
-                const uint32_t diff = (uint32_t)((ix ^ jx) | (iy ^ jy) | (iz ^ jz));
-                // levels shared by the old and new path: clz over the 24-bit codes (diff == 0: all 24)
-                // (diff == 0: all 24); + 1 = the first level that differs, folded into the shift
-                const uint32_t c1 = (uint32_t)__clz((int)((diff << 7) | 0x40u));
-                ix = jx; iy = jy; iz = jz;
-                st |= ST_DESC;
-                const uint32_t r = min(c1, L);  // (L <= SMAX: the walk stops there)
-                if (CNT) {  // levels r and below belong to a new path
-                    satm &= (1u << r) - 1u;
-                }
-                restart_at(r);
             }
         }
         if (DBG) c_step += (uint32_t)(__builtin_amdgcn_s_memtime() - c_mark);
@@ -969,12 +1064,12 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : 6)) void trace_stac
         }
     }
     if (DBG) {  // the rays that finish last: their step counts tell whether the tail is long rays or late starts
-        uint32_t last = (st & ST_PENDING) ? (st & 0xFFu) : 0u;
+        uint32_t last = sabs(stf) == ST_PENDING ? (uint32_t)stepsf : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) last = max(last, (uint32_t)__shfl_xor((int)last, o));
         dbg_iters = last;
     }
-    if (st & ST_PENDING) flush_record(false);
+    if (sabs(stf) == ST_PENDING) flush_record(false);
     if (DBG && lane == 0) {
         uint64_t t_end = __builtin_amdgcn_s_memrealtime();
         uint32_t *d = a.debug + 16u * wave_id;
@@ -1422,8 +1517,8 @@ hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint3
 
 constexpr int kStackBlock = 256;
 constexpr int kStackLevels = 12;      // default: resolves levels up to 3 + 1 + 12 = 16
-constexpr int kStackLevelsDeep = 19;  // deep trees: up to level 23
-constexpr int kPoolWordsHost = 11;
+constexpr int kStackLevelsDeep = 18;  // deep trees: up to level 22 = kPathBits - 1
+constexpr int kPoolWordsHost = kPoolWords;
 
 int stack_max_depth(bool deep) { return kTopLevels + 1 + (deep ? kStackLevelsDeep : kStackLevels); }
 
@@ -1438,7 +1533,7 @@ static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipS
                                          : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, false>)
                            : (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false>
                                          : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false>));
-    size_t lds_bytes = (size_t)((1 << (3 * kTopLevels)) + (NS + 1) * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
+    size_t lds_bytes = (size_t)((SVO_TOP_IN_LDS ? (1 << (3 * kTopLevels)) : 0) + NS * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
                                 (args.count_nodes ? (kStackBlock / 64) * kCountQueue + kSatTags + (1 << (3 * kTopLevels)) / 8 : 0)) * sizeof(uint32_t);
     // cached per context (= per device): [deep stack?][fused shadows?][counting instantiation?]
     int &blocks_per_cu = li.occupancy[(args.debug ? 8 : 0) + (NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];

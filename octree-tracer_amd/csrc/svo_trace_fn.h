@@ -291,11 +291,14 @@ __device__ __forceinline__ int32_t cvt_floor_neg_i32(float x) {
     return r;
 }
 
-// path code of a finite position given in grid units (|g| <= 2^24), clamped into the cube like path_code()
+// Path code of a finite position given in grid units (|g| <= 2^(D+1)), clamped into the cube like path_code(), in the form
+// the STACK kernel keeps it: the bits of the f32 number 2^D + code (0x4B000000 | code for D = 23).  Bit D - l of that word is
+// the child choice at level l, and the same word read as a float takes part in the step's arithmetic without a conversion.
 template <bool GE>
-__device__ __forceinline__ int32_t entry_code(float g) {
-    const int32_t i = GE ? cvt_floor_i32(g) + 8388608 : 8388607 - cvt_floor_neg_i32(g);
-    return min(max(i, 0), 0x00FFFFFF);
+__device__ __forceinline__ uint32_t entry_magic(float g) {
+    constexpr int32_t kHalf = 1 << (kPathBits - 1), kMax = (1 << kPathBits) - 1;
+    const int32_t i = GE ? cvt_floor_i32(g) + kHalf : (kHalf - 1) - cvt_floor_neg_i32(g);
+    return __float_as_uint((float)(1 << kPathBits)) | (uint32_t)min(max(i, 0), kMax);
 }
 
 __device__ __forceinline__ float copysign_bits(float mag, float sgn) {
@@ -311,23 +314,22 @@ __device__ __forceinline__ bool clean_component(float p, float d) {
     return p_ok && d_ok;  // NaN fails both
 }
 
-// Per-lane state word: bits 0..7 steps | 8..12 leaf depth L | 13..15 step mask (axes of the last step's
-// normal) | 16 normal-is-entry-normal | 31 active | 30 needs descent (only ever set together with active) | 21 record pending | 22..24 how it ended
-constexpr uint32_t ST_L_SHIFT = 8, ST_M_SHIFT = 13;
-constexpr uint32_t ST_ENTRY = 1u << 16, ST_ACTIVE = 1u << 31, ST_DESC = 1u << 30;
-constexpr uint32_t ST_SHADOW = 1u << 17;  // SHD instantiation: the lane traces the shadow ray of the pixel in `out`
-// a finished ray keeps its state until the lane is refilled: record not yet written + how it ended
-constexpr uint32_t ST_PENDING = 1u << 21, ST_F_TOODEEP = 1u << 22, ST_F_SOLID = 1u << 23, ST_F_INB = 1u << 24;
-constexpr uint32_t ST_L_MASK = 31u << ST_L_SHIFT, ST_M_MASK = 7u << ST_M_SHIFT;
+// Per-lane state of the STACK kernel, kept as a FLOAT (round 4: on gfx950 the plain f32 instructions -- add, mul, fma, also with
+// the clamp modifier -- issue beside the integer / compare / conversion instructions, which is where this kernel is bound; an
+// integer state word cost a handful of those per round): 0 no ray, 1 a finished ray whose record is not written yet, 2 at its
+// leaf, 4 needs a descent; negative: the lane traces the shadow ray of the pixel in `out` (SHD instantiation).  Transitions are
+// multiplications (x 2, x 0.5), which keep the sign.  Steps, the last step's mask and the leaf's level live in registers of
+// their own (stepsf, nmf, sh).
+constexpr float ST_IDLE = 0.0f, ST_PENDING = 1.0f, ST_LEAF = 2.0f, ST_DESC = 4.0f;
 
 // Ray pool: a wave generates the rays of up to 64 work items at once, with every lane busy (lanes that
 // are still traversing compute a ray for somebody else), compacts the ones that enter the cube into LDS,
 // and idle lanes later pick them up.  Ray generation and set-up (2 mat-vecs, 14 IEEE divisions, a square
 // root) are thereby paid once per 64 rays at full lane utilisation instead of on
-// every refill.  Pool record: P.xyz, Dr.xyz, Y.xyz (position, biased direction and its reciprocal, all in
-// grid units, see below), dist, out | entry normal code << 26.  (The entry path codes are recomputed at pick-up:
-// 11 words per ray keep a workgroup at 26 KiB of LDS, i.e. 6 workgroups per CU.)
-constexpr int kPoolWords = 11;
+// every refill.  Pool record: P.xyz, Dr.xyz (position and biased direction in grid units), dist, out | entry normal code << 26.
+// (The entry path codes and the reciprocals of the direction are recomputed at pick-up: 8 words per ray keep a workgroup at
+// 22 KiB of LDS, i.e. 7 workgroups per CU.)
+constexpr int kPoolWords = 8;
 constexpr int kCountQueue = 128;  // CNT: queued (word, visits) pairs per wave
 constexpr int kSatTags = 512;     // CNT: words known to be saturated, direct-mapped, per workgroup
 

@@ -411,6 +411,53 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned *out, unsigned long 
             OPS("v_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\t");
         } else if (KIND == 94) {
             OPS("v_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\t");
+        } else if (KIND == 95) {
+            OPS("v_floor_f32 %0, %0\n\tv_floor_f32 %1, %1\n\tv_floor_f32 %2, %2\n\tv_floor_f32 %3, %3\n\tv_floor_f32 %4, %4\n\tv_floor_f32 %5, %5\n\tv_floor_f32 %6, %6\n\tv_floor_f32 %7, %7\n\tv_floor_f32 %0, %0\n\tv_floor_f32 %1, %1\n\tv_floor_f32 %2, %2\n\tv_floor_f32 %3, %3\n\tv_floor_f32 %4, %4\n\tv_floor_f32 %5, %5\n\tv_floor_f32 %6, %6\n\tv_floor_f32 %7, %7\n\tv_floor_f32 %0, %0\n\tv_floor_f32 %1, %1\n\tv_floor_f32 %2, %2\n\tv_floor_f32 %3, %3\n\tv_floor_f32 %4, %4\n\tv_floor_f32 %5, %5\n\tv_floor_f32 %6, %6\n\tv_floor_f32 %7, %7\n\tv_floor_f32 %0, %0\n\tv_floor_f32 %1, %1\n\tv_floor_f32 %2, %2\n\tv_floor_f32 %3, %3\n\tv_floor_f32 %4, %4\n\tv_floor_f32 %5, %5\n\tv_floor_f32 %6, %6\n\tv_floor_f32 %7, %7\n\tv_floor_f32 %0, %0\n\tv_floor_f32 %1, %1\n\tv_floor_f32 %2, %2\n\tv_floor_f32 %3, %3\n\tv_floor_f32 %4, %4\n\tv_floor_f32 %5, %5\n\tv_floor_f32 %6, %6\n\tv_floor_f32 %7, %7\n\tv_floor_f32 %0, %0\n\tv_floor_f32 %1, %1\n\tv_floor_f32 %2, %2\n\tv_floor_f32 %3, %3\n\tv_floor_f32 %4, %4\n\tv_floor_f32 %5, %5\n\tv_floor_f32 %6, %6\n\tv_floor_f32 %7, %7\n\tv_floor_f32 %0, %0\n\tv_floor_f32 %1, %1\n\tv_floor_f32 %2, %2\n\tv_floor_f32 %3, %3\n\tv_floor_f32 %4, %4\n\tv_floor_f32 %5, %5\n\tv_floor_f32 %6, %6\n\tv_floor_f32 %7, %7\n\tv_floor_f32 %0, %0\n\tv_floor_f32 %1, %1\n\tv_floor_f32 %2, %2\n\tv_floor_f32 %3, %3\n\tv_floor_f32 %4, %4\n\tv_floor_f32 %5, %5\n\tv_floor_f32 %6, %6\n\tv_floor_f32 %7, %7\n\t");
+        } else if (KIND == 96) {
+            OPS("v_ldexp_f32 %0, %0, %18\n\tv_ldexp_f32 %1, %1, %18\n\tv_ldexp_f32 %2, %2, %18\n\tv_ldexp_f32 %3, %3, %18\n\tv_ldexp_f32 %4, %4, %18\n\tv_ldexp_f32 %5, %5, %18\n\tv_ldexp_f32 %6, %6, %18\n\tv_ldexp_f32 %7, %7, %18\n\tv_ldexp_f32 %0, %0, %18\n\tv_ldexp_f32 %1, %1, %18\n\tv_ldexp_f32 %2, %2, %18\n\tv_ldexp_f32 %3, %3, %18\n\tv_ldexp_f32 %4, %4, %18\n\tv_ldexp_f32 %5, %5, %18\n\tv_ldexp_f32 %6, %6, %18\n\tv_ldexp_f32 %7, %7, %18\n\tv_ldexp_f32 %0, %0, %18\n\tv_ldexp_f32 %1, %1, %18\n\tv_ldexp_f32 %2, %2, %18\n\tv_ldexp_f32 %3, %3, %18\n\tv_ldexp_f32 %4, %4, %18\n\tv_ldexp_f32 %5, %5, %18\n\tv_ldexp_f32 %6, %6, %18\n\tv_ldexp_f32 %7, %7, %18\n\tv_ldexp_f32 %0, %0, %18\n\tv_ldexp_f32 %1, %1, %18\n\tv_ldexp_f32 %2, %2, %18\n\tv_ldexp_f32 %3, %3, %18\n\tv_ldexp_f32 %4, %4, %18\n\tv_ldexp_f32 %5, %5, %18\n\tv_ldexp_f32 %6, %6, %18\n\tv_ldexp_f32 %7, %7, %18\n\tv_ldexp_f32 %0, %0, %18\n\tv_ldexp_f32 %1, %1, %18\n\tv_ldexp_f32 %2, %2, %18\n\tv_ldexp_f32 %3, %3, %18\n\tv_ldexp_f32 %4, %4, %18\n\tv_ldexp_f32 %5, %5, %18\n\tv_ldexp_f32 %6, %6, %18\n\tv_ldexp_f32 %7, %7, %18\n\tv_ldexp_f32 %0, %0, %18\n\tv_ldexp_f32 %1, %1, %18\n\tv_ldexp_f32 %2, %2, %18\n\tv_ldexp_f32 %3, %3, %18\n\tv_ldexp_f32 %4, %4, %18\n\tv_ldexp_f32 %5, %5, %18\n\tv_ldexp_f32 %6, %6, %18\n\tv_ldexp_f32 %7, %7, %18\n\tv_ldexp_f32 %0, %0, %18\n\tv_ldexp_f32 %1, %1, %18\n\tv_ldexp_f32 %2, %2, %18\n\tv_ldexp_f32 %3, %3, %18\n\tv_ldexp_f32 %4, %4, %18\n\tv_ldexp_f32 %5, %5, %18\n\tv_ldexp_f32 %6, %6, %18\n\tv_ldexp_f32 %7, %7, %18\n\tv_ldexp_f32 %0, %0, %18\n\tv_ldexp_f32 %1, %1, %18\n\tv_ldexp_f32 %2, %2, %18\n\tv_ldexp_f32 %3, %3, %18\n\tv_ldexp_f32 %4, %4, %18\n\tv_ldexp_f32 %5, %5, %18\n\tv_ldexp_f32 %6, %6, %18\n\tv_ldexp_f32 %7, %7, %18\n\t");
+        } else if (KIND == 97) {
+            OPS("v_fract_f32 %0, %0\n\tv_fract_f32 %1, %1\n\tv_fract_f32 %2, %2\n\tv_fract_f32 %3, %3\n\tv_fract_f32 %4, %4\n\tv_fract_f32 %5, %5\n\tv_fract_f32 %6, %6\n\tv_fract_f32 %7, %7\n\tv_fract_f32 %0, %0\n\tv_fract_f32 %1, %1\n\tv_fract_f32 %2, %2\n\tv_fract_f32 %3, %3\n\tv_fract_f32 %4, %4\n\tv_fract_f32 %5, %5\n\tv_fract_f32 %6, %6\n\tv_fract_f32 %7, %7\n\tv_fract_f32 %0, %0\n\tv_fract_f32 %1, %1\n\tv_fract_f32 %2, %2\n\tv_fract_f32 %3, %3\n\tv_fract_f32 %4, %4\n\tv_fract_f32 %5, %5\n\tv_fract_f32 %6, %6\n\tv_fract_f32 %7, %7\n\tv_fract_f32 %0, %0\n\tv_fract_f32 %1, %1\n\tv_fract_f32 %2, %2\n\tv_fract_f32 %3, %3\n\tv_fract_f32 %4, %4\n\tv_fract_f32 %5, %5\n\tv_fract_f32 %6, %6\n\tv_fract_f32 %7, %7\n\tv_fract_f32 %0, %0\n\tv_fract_f32 %1, %1\n\tv_fract_f32 %2, %2\n\tv_fract_f32 %3, %3\n\tv_fract_f32 %4, %4\n\tv_fract_f32 %5, %5\n\tv_fract_f32 %6, %6\n\tv_fract_f32 %7, %7\n\tv_fract_f32 %0, %0\n\tv_fract_f32 %1, %1\n\tv_fract_f32 %2, %2\n\tv_fract_f32 %3, %3\n\tv_fract_f32 %4, %4\n\tv_fract_f32 %5, %5\n\tv_fract_f32 %6, %6\n\tv_fract_f32 %7, %7\n\tv_fract_f32 %0, %0\n\tv_fract_f32 %1, %1\n\tv_fract_f32 %2, %2\n\tv_fract_f32 %3, %3\n\tv_fract_f32 %4, %4\n\tv_fract_f32 %5, %5\n\tv_fract_f32 %6, %6\n\tv_fract_f32 %7, %7\n\tv_fract_f32 %0, %0\n\tv_fract_f32 %1, %1\n\tv_fract_f32 %2, %2\n\tv_fract_f32 %3, %3\n\tv_fract_f32 %4, %4\n\tv_fract_f32 %5, %5\n\tv_fract_f32 %6, %6\n\tv_fract_f32 %7, %7\n\t");
+        } else if (KIND == 98) {
+            OPS("v_trunc_f32 %0, %0\n\tv_trunc_f32 %1, %1\n\tv_trunc_f32 %2, %2\n\tv_trunc_f32 %3, %3\n\tv_trunc_f32 %4, %4\n\tv_trunc_f32 %5, %5\n\tv_trunc_f32 %6, %6\n\tv_trunc_f32 %7, %7\n\tv_trunc_f32 %0, %0\n\tv_trunc_f32 %1, %1\n\tv_trunc_f32 %2, %2\n\tv_trunc_f32 %3, %3\n\tv_trunc_f32 %4, %4\n\tv_trunc_f32 %5, %5\n\tv_trunc_f32 %6, %6\n\tv_trunc_f32 %7, %7\n\tv_trunc_f32 %0, %0\n\tv_trunc_f32 %1, %1\n\tv_trunc_f32 %2, %2\n\tv_trunc_f32 %3, %3\n\tv_trunc_f32 %4, %4\n\tv_trunc_f32 %5, %5\n\tv_trunc_f32 %6, %6\n\tv_trunc_f32 %7, %7\n\tv_trunc_f32 %0, %0\n\tv_trunc_f32 %1, %1\n\tv_trunc_f32 %2, %2\n\tv_trunc_f32 %3, %3\n\tv_trunc_f32 %4, %4\n\tv_trunc_f32 %5, %5\n\tv_trunc_f32 %6, %6\n\tv_trunc_f32 %7, %7\n\tv_trunc_f32 %0, %0\n\tv_trunc_f32 %1, %1\n\tv_trunc_f32 %2, %2\n\tv_trunc_f32 %3, %3\n\tv_trunc_f32 %4, %4\n\tv_trunc_f32 %5, %5\n\tv_trunc_f32 %6, %6\n\tv_trunc_f32 %7, %7\n\tv_trunc_f32 %0, %0\n\tv_trunc_f32 %1, %1\n\tv_trunc_f32 %2, %2\n\tv_trunc_f32 %3, %3\n\tv_trunc_f32 %4, %4\n\tv_trunc_f32 %5, %5\n\tv_trunc_f32 %6, %6\n\tv_trunc_f32 %7, %7\n\tv_trunc_f32 %0, %0\n\tv_trunc_f32 %1, %1\n\tv_trunc_f32 %2, %2\n\tv_trunc_f32 %3, %3\n\tv_trunc_f32 %4, %4\n\tv_trunc_f32 %5, %5\n\tv_trunc_f32 %6, %6\n\tv_trunc_f32 %7, %7\n\tv_trunc_f32 %0, %0\n\tv_trunc_f32 %1, %1\n\tv_trunc_f32 %2, %2\n\tv_trunc_f32 %3, %3\n\tv_trunc_f32 %4, %4\n\tv_trunc_f32 %5, %5\n\tv_trunc_f32 %6, %6\n\tv_trunc_f32 %7, %7\n\t");
+        } else if (KIND == 99) {
+            OPS("v_rndne_f32 %0, %0\n\tv_rndne_f32 %1, %1\n\tv_rndne_f32 %2, %2\n\tv_rndne_f32 %3, %3\n\tv_rndne_f32 %4, %4\n\tv_rndne_f32 %5, %5\n\tv_rndne_f32 %6, %6\n\tv_rndne_f32 %7, %7\n\tv_rndne_f32 %0, %0\n\tv_rndne_f32 %1, %1\n\tv_rndne_f32 %2, %2\n\tv_rndne_f32 %3, %3\n\tv_rndne_f32 %4, %4\n\tv_rndne_f32 %5, %5\n\tv_rndne_f32 %6, %6\n\tv_rndne_f32 %7, %7\n\tv_rndne_f32 %0, %0\n\tv_rndne_f32 %1, %1\n\tv_rndne_f32 %2, %2\n\tv_rndne_f32 %3, %3\n\tv_rndne_f32 %4, %4\n\tv_rndne_f32 %5, %5\n\tv_rndne_f32 %6, %6\n\tv_rndne_f32 %7, %7\n\tv_rndne_f32 %0, %0\n\tv_rndne_f32 %1, %1\n\tv_rndne_f32 %2, %2\n\tv_rndne_f32 %3, %3\n\tv_rndne_f32 %4, %4\n\tv_rndne_f32 %5, %5\n\tv_rndne_f32 %6, %6\n\tv_rndne_f32 %7, %7\n\tv_rndne_f32 %0, %0\n\tv_rndne_f32 %1, %1\n\tv_rndne_f32 %2, %2\n\tv_rndne_f32 %3, %3\n\tv_rndne_f32 %4, %4\n\tv_rndne_f32 %5, %5\n\tv_rndne_f32 %6, %6\n\tv_rndne_f32 %7, %7\n\tv_rndne_f32 %0, %0\n\tv_rndne_f32 %1, %1\n\tv_rndne_f32 %2, %2\n\tv_rndne_f32 %3, %3\n\tv_rndne_f32 %4, %4\n\tv_rndne_f32 %5, %5\n\tv_rndne_f32 %6, %6\n\tv_rndne_f32 %7, %7\n\tv_rndne_f32 %0, %0\n\tv_rndne_f32 %1, %1\n\tv_rndne_f32 %2, %2\n\tv_rndne_f32 %3, %3\n\tv_rndne_f32 %4, %4\n\tv_rndne_f32 %5, %5\n\tv_rndne_f32 %6, %6\n\tv_rndne_f32 %7, %7\n\tv_rndne_f32 %0, %0\n\tv_rndne_f32 %1, %1\n\tv_rndne_f32 %2, %2\n\tv_rndne_f32 %3, %3\n\tv_rndne_f32 %4, %4\n\tv_rndne_f32 %5, %5\n\tv_rndne_f32 %6, %6\n\tv_rndne_f32 %7, %7\n\t");
+        } else if (KIND == 100) {
+            OPS("v_mul_f32_e64 %0, %0, %17 clamp\n\tv_mul_f32_e64 %1, %1, %17 clamp\n\tv_mul_f32_e64 %2, %2, %17 clamp\n\tv_mul_f32_e64 %3, %3, %17 clamp\n\tv_mul_f32_e64 %4, %4, %17 clamp\n\tv_mul_f32_e64 %5, %5, %17 clamp\n\tv_mul_f32_e64 %6, %6, %17 clamp\n\tv_mul_f32_e64 %7, %7, %17 clamp\n\tv_mul_f32_e64 %0, %0, %17 clamp\n\tv_mul_f32_e64 %1, %1, %17 clamp\n\tv_mul_f32_e64 %2, %2, %17 clamp\n\tv_mul_f32_e64 %3, %3, %17 clamp\n\tv_mul_f32_e64 %4, %4, %17 clamp\n\tv_mul_f32_e64 %5, %5, %17 clamp\n\tv_mul_f32_e64 %6, %6, %17 clamp\n\tv_mul_f32_e64 %7, %7, %17 clamp\n\tv_mul_f32_e64 %0, %0, %17 clamp\n\tv_mul_f32_e64 %1, %1, %17 clamp\n\tv_mul_f32_e64 %2, %2, %17 clamp\n\tv_mul_f32_e64 %3, %3, %17 clamp\n\tv_mul_f32_e64 %4, %4, %17 clamp\n\tv_mul_f32_e64 %5, %5, %17 clamp\n\tv_mul_f32_e64 %6, %6, %17 clamp\n\tv_mul_f32_e64 %7, %7, %17 clamp\n\tv_mul_f32_e64 %0, %0, %17 clamp\n\tv_mul_f32_e64 %1, %1, %17 clamp\n\tv_mul_f32_e64 %2, %2, %17 clamp\n\tv_mul_f32_e64 %3, %3, %17 clamp\n\tv_mul_f32_e64 %4, %4, %17 clamp\n\tv_mul_f32_e64 %5, %5, %17 clamp\n\tv_mul_f32_e64 %6, %6, %17 clamp\n\tv_mul_f32_e64 %7, %7, %17 clamp\n\tv_mul_f32_e64 %0, %0, %17 clamp\n\tv_mul_f32_e64 %1, %1, %17 clamp\n\tv_mul_f32_e64 %2, %2, %17 clamp\n\tv_mul_f32_e64 %3, %3, %17 clamp\n\tv_mul_f32_e64 %4, %4, %17 clamp\n\tv_mul_f32_e64 %5, %5, %17 clamp\n\tv_mul_f32_e64 %6, %6, %17 clamp\n\tv_mul_f32_e64 %7, %7, %17 clamp\n\tv_mul_f32_e64 %0, %0, %17 clamp\n\tv_mul_f32_e64 %1, %1, %17 clamp\n\tv_mul_f32_e64 %2, %2, %17 clamp\n\tv_mul_f32_e64 %3, %3, %17 clamp\n\tv_mul_f32_e64 %4, %4, %17 clamp\n\tv_mul_f32_e64 %5, %5, %17 clamp\n\tv_mul_f32_e64 %6, %6, %17 clamp\n\tv_mul_f32_e64 %7, %7, %17 clamp\n\tv_mul_f32_e64 %0, %0, %17 clamp\n\tv_mul_f32_e64 %1, %1, %17 clamp\n\tv_mul_f32_e64 %2, %2, %17 clamp\n\tv_mul_f32_e64 %3, %3, %17 clamp\n\tv_mul_f32_e64 %4, %4, %17 clamp\n\tv_mul_f32_e64 %5, %5, %17 clamp\n\tv_mul_f32_e64 %6, %6, %17 clamp\n\tv_mul_f32_e64 %7, %7, %17 clamp\n\tv_mul_f32_e64 %0, %0, %17 clamp\n\tv_mul_f32_e64 %1, %1, %17 clamp\n\tv_mul_f32_e64 %2, %2, %17 clamp\n\tv_mul_f32_e64 %3, %3, %17 clamp\n\tv_mul_f32_e64 %4, %4, %17 clamp\n\tv_mul_f32_e64 %5, %5, %17 clamp\n\tv_mul_f32_e64 %6, %6, %17 clamp\n\tv_mul_f32_e64 %7, %7, %17 clamp\n\t");
+        } else if (KIND == 101) {
+            OPS("v_fma_f32 %0, %0, %17, %18 clamp\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_fma_f32 %2, %2, %17, %18 clamp\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_fma_f32 %4, %4, %17, %18 clamp\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_fma_f32 %6, %6, %17, %18 clamp\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_fma_f32 %0, %0, %17, %18 clamp\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_fma_f32 %2, %2, %17, %18 clamp\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_fma_f32 %4, %4, %17, %18 clamp\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_fma_f32 %6, %6, %17, %18 clamp\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_fma_f32 %0, %0, %17, %18 clamp\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_fma_f32 %2, %2, %17, %18 clamp\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_fma_f32 %4, %4, %17, %18 clamp\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_fma_f32 %6, %6, %17, %18 clamp\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_fma_f32 %0, %0, %17, %18 clamp\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_fma_f32 %2, %2, %17, %18 clamp\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_fma_f32 %4, %4, %17, %18 clamp\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_fma_f32 %6, %6, %17, %18 clamp\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_fma_f32 %0, %0, %17, %18 clamp\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_fma_f32 %2, %2, %17, %18 clamp\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_fma_f32 %4, %4, %17, %18 clamp\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_fma_f32 %6, %6, %17, %18 clamp\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_fma_f32 %0, %0, %17, %18 clamp\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_fma_f32 %2, %2, %17, %18 clamp\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_fma_f32 %4, %4, %17, %18 clamp\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_fma_f32 %6, %6, %17, %18 clamp\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_fma_f32 %0, %0, %17, %18 clamp\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_fma_f32 %2, %2, %17, %18 clamp\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_fma_f32 %4, %4, %17, %18 clamp\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_fma_f32 %6, %6, %17, %18 clamp\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_fma_f32 %0, %0, %17, %18 clamp\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_fma_f32 %2, %2, %17, %18 clamp\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_fma_f32 %4, %4, %17, %18 clamp\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_fma_f32 %6, %6, %17, %18 clamp\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\t");
+        } else if (KIND == 102) {
+            OPS("v_frexp_exp_i32_f32 %0, %0\n\tv_frexp_exp_i32_f32 %1, %1\n\tv_frexp_exp_i32_f32 %2, %2\n\tv_frexp_exp_i32_f32 %3, %3\n\tv_frexp_exp_i32_f32 %4, %4\n\tv_frexp_exp_i32_f32 %5, %5\n\tv_frexp_exp_i32_f32 %6, %6\n\tv_frexp_exp_i32_f32 %7, %7\n\tv_frexp_exp_i32_f32 %0, %0\n\tv_frexp_exp_i32_f32 %1, %1\n\tv_frexp_exp_i32_f32 %2, %2\n\tv_frexp_exp_i32_f32 %3, %3\n\tv_frexp_exp_i32_f32 %4, %4\n\tv_frexp_exp_i32_f32 %5, %5\n\tv_frexp_exp_i32_f32 %6, %6\n\tv_frexp_exp_i32_f32 %7, %7\n\tv_frexp_exp_i32_f32 %0, %0\n\tv_frexp_exp_i32_f32 %1, %1\n\tv_frexp_exp_i32_f32 %2, %2\n\tv_frexp_exp_i32_f32 %3, %3\n\tv_frexp_exp_i32_f32 %4, %4\n\tv_frexp_exp_i32_f32 %5, %5\n\tv_frexp_exp_i32_f32 %6, %6\n\tv_frexp_exp_i32_f32 %7, %7\n\tv_frexp_exp_i32_f32 %0, %0\n\tv_frexp_exp_i32_f32 %1, %1\n\tv_frexp_exp_i32_f32 %2, %2\n\tv_frexp_exp_i32_f32 %3, %3\n\tv_frexp_exp_i32_f32 %4, %4\n\tv_frexp_exp_i32_f32 %5, %5\n\tv_frexp_exp_i32_f32 %6, %6\n\tv_frexp_exp_i32_f32 %7, %7\n\tv_frexp_exp_i32_f32 %0, %0\n\tv_frexp_exp_i32_f32 %1, %1\n\tv_frexp_exp_i32_f32 %2, %2\n\tv_frexp_exp_i32_f32 %3, %3\n\tv_frexp_exp_i32_f32 %4, %4\n\tv_frexp_exp_i32_f32 %5, %5\n\tv_frexp_exp_i32_f32 %6, %6\n\tv_frexp_exp_i32_f32 %7, %7\n\tv_frexp_exp_i32_f32 %0, %0\n\tv_frexp_exp_i32_f32 %1, %1\n\tv_frexp_exp_i32_f32 %2, %2\n\tv_frexp_exp_i32_f32 %3, %3\n\tv_frexp_exp_i32_f32 %4, %4\n\tv_frexp_exp_i32_f32 %5, %5\n\tv_frexp_exp_i32_f32 %6, %6\n\tv_frexp_exp_i32_f32 %7, %7\n\tv_frexp_exp_i32_f32 %0, %0\n\tv_frexp_exp_i32_f32 %1, %1\n\tv_frexp_exp_i32_f32 %2, %2\n\tv_frexp_exp_i32_f32 %3, %3\n\tv_frexp_exp_i32_f32 %4, %4\n\tv_frexp_exp_i32_f32 %5, %5\n\tv_frexp_exp_i32_f32 %6, %6\n\tv_frexp_exp_i32_f32 %7, %7\n\tv_frexp_exp_i32_f32 %0, %0\n\tv_frexp_exp_i32_f32 %1, %1\n\tv_frexp_exp_i32_f32 %2, %2\n\tv_frexp_exp_i32_f32 %3, %3\n\tv_frexp_exp_i32_f32 %4, %4\n\tv_frexp_exp_i32_f32 %5, %5\n\tv_frexp_exp_i32_f32 %6, %6\n\tv_frexp_exp_i32_f32 %7, %7\n\t");
+        } else if (KIND == 103) {
+            OPS("v_cvt_u32_f32 %0, %0\n\tv_cvt_u32_f32 %1, %1\n\tv_cvt_u32_f32 %2, %2\n\tv_cvt_u32_f32 %3, %3\n\tv_cvt_u32_f32 %4, %4\n\tv_cvt_u32_f32 %5, %5\n\tv_cvt_u32_f32 %6, %6\n\tv_cvt_u32_f32 %7, %7\n\tv_cvt_u32_f32 %0, %0\n\tv_cvt_u32_f32 %1, %1\n\tv_cvt_u32_f32 %2, %2\n\tv_cvt_u32_f32 %3, %3\n\tv_cvt_u32_f32 %4, %4\n\tv_cvt_u32_f32 %5, %5\n\tv_cvt_u32_f32 %6, %6\n\tv_cvt_u32_f32 %7, %7\n\tv_cvt_u32_f32 %0, %0\n\tv_cvt_u32_f32 %1, %1\n\tv_cvt_u32_f32 %2, %2\n\tv_cvt_u32_f32 %3, %3\n\tv_cvt_u32_f32 %4, %4\n\tv_cvt_u32_f32 %5, %5\n\tv_cvt_u32_f32 %6, %6\n\tv_cvt_u32_f32 %7, %7\n\tv_cvt_u32_f32 %0, %0\n\tv_cvt_u32_f32 %1, %1\n\tv_cvt_u32_f32 %2, %2\n\tv_cvt_u32_f32 %3, %3\n\tv_cvt_u32_f32 %4, %4\n\tv_cvt_u32_f32 %5, %5\n\tv_cvt_u32_f32 %6, %6\n\tv_cvt_u32_f32 %7, %7\n\tv_cvt_u32_f32 %0, %0\n\tv_cvt_u32_f32 %1, %1\n\tv_cvt_u32_f32 %2, %2\n\tv_cvt_u32_f32 %3, %3\n\tv_cvt_u32_f32 %4, %4\n\tv_cvt_u32_f32 %5, %5\n\tv_cvt_u32_f32 %6, %6\n\tv_cvt_u32_f32 %7, %7\n\tv_cvt_u32_f32 %0, %0\n\tv_cvt_u32_f32 %1, %1\n\tv_cvt_u32_f32 %2, %2\n\tv_cvt_u32_f32 %3, %3\n\tv_cvt_u32_f32 %4, %4\n\tv_cvt_u32_f32 %5, %5\n\tv_cvt_u32_f32 %6, %6\n\tv_cvt_u32_f32 %7, %7\n\tv_cvt_u32_f32 %0, %0\n\tv_cvt_u32_f32 %1, %1\n\tv_cvt_u32_f32 %2, %2\n\tv_cvt_u32_f32 %3, %3\n\tv_cvt_u32_f32 %4, %4\n\tv_cvt_u32_f32 %5, %5\n\tv_cvt_u32_f32 %6, %6\n\tv_cvt_u32_f32 %7, %7\n\tv_cvt_u32_f32 %0, %0\n\tv_cvt_u32_f32 %1, %1\n\tv_cvt_u32_f32 %2, %2\n\tv_cvt_u32_f32 %3, %3\n\tv_cvt_u32_f32 %4, %4\n\tv_cvt_u32_f32 %5, %5\n\tv_cvt_u32_f32 %6, %6\n\tv_cvt_u32_f32 %7, %7\n\t");
+        } else if (KIND == 104) {
+            OPS("v_mul_f32 %0, 0x7e800000, %0\n\tv_mul_f32 %1, 0x7e800000, %1\n\tv_mul_f32 %2, 0x7e800000, %2\n\tv_mul_f32 %3, 0x7e800000, %3\n\tv_mul_f32 %4, 0x7e800000, %4\n\tv_mul_f32 %5, 0x7e800000, %5\n\tv_mul_f32 %6, 0x7e800000, %6\n\tv_mul_f32 %7, 0x7e800000, %7\n\tv_mul_f32 %0, 0x7e800000, %0\n\tv_mul_f32 %1, 0x7e800000, %1\n\tv_mul_f32 %2, 0x7e800000, %2\n\tv_mul_f32 %3, 0x7e800000, %3\n\tv_mul_f32 %4, 0x7e800000, %4\n\tv_mul_f32 %5, 0x7e800000, %5\n\tv_mul_f32 %6, 0x7e800000, %6\n\tv_mul_f32 %7, 0x7e800000, %7\n\tv_mul_f32 %0, 0x7e800000, %0\n\tv_mul_f32 %1, 0x7e800000, %1\n\tv_mul_f32 %2, 0x7e800000, %2\n\tv_mul_f32 %3, 0x7e800000, %3\n\tv_mul_f32 %4, 0x7e800000, %4\n\tv_mul_f32 %5, 0x7e800000, %5\n\tv_mul_f32 %6, 0x7e800000, %6\n\tv_mul_f32 %7, 0x7e800000, %7\n\tv_mul_f32 %0, 0x7e800000, %0\n\tv_mul_f32 %1, 0x7e800000, %1\n\tv_mul_f32 %2, 0x7e800000, %2\n\tv_mul_f32 %3, 0x7e800000, %3\n\tv_mul_f32 %4, 0x7e800000, %4\n\tv_mul_f32 %5, 0x7e800000, %5\n\tv_mul_f32 %6, 0x7e800000, %6\n\tv_mul_f32 %7, 0x7e800000, %7\n\tv_mul_f32 %0, 0x7e800000, %0\n\tv_mul_f32 %1, 0x7e800000, %1\n\tv_mul_f32 %2, 0x7e800000, %2\n\tv_mul_f32 %3, 0x7e800000, %3\n\tv_mul_f32 %4, 0x7e800000, %4\n\tv_mul_f32 %5, 0x7e800000, %5\n\tv_mul_f32 %6, 0x7e800000, %6\n\tv_mul_f32 %7, 0x7e800000, %7\n\tv_mul_f32 %0, 0x7e800000, %0\n\tv_mul_f32 %1, 0x7e800000, %1\n\tv_mul_f32 %2, 0x7e800000, %2\n\tv_mul_f32 %3, 0x7e800000, %3\n\tv_mul_f32 %4, 0x7e800000, %4\n\tv_mul_f32 %5, 0x7e800000, %5\n\tv_mul_f32 %6, 0x7e800000, %6\n\tv_mul_f32 %7, 0x7e800000, %7\n\tv_mul_f32 %0, 0x7e800000, %0\n\tv_mul_f32 %1, 0x7e800000, %1\n\tv_mul_f32 %2, 0x7e800000, %2\n\tv_mul_f32 %3, 0x7e800000, %3\n\tv_mul_f32 %4, 0x7e800000, %4\n\tv_mul_f32 %5, 0x7e800000, %5\n\tv_mul_f32 %6, 0x7e800000, %6\n\tv_mul_f32 %7, 0x7e800000, %7\n\tv_mul_f32 %0, 0x7e800000, %0\n\tv_mul_f32 %1, 0x7e800000, %1\n\tv_mul_f32 %2, 0x7e800000, %2\n\tv_mul_f32 %3, 0x7e800000, %3\n\tv_mul_f32 %4, 0x7e800000, %4\n\tv_mul_f32 %5, 0x7e800000, %5\n\tv_mul_f32 %6, 0x7e800000, %6\n\tv_mul_f32 %7, 0x7e800000, %7\n\t");
+        } else if (KIND == 105) {
+            OPS("v_floor_f32 %0, %0\n\tv_add_f32 %1, %1, %17\n\tv_mul_f32 %2, %2, %17\n\tv_fma_f32 %3, %3, %17, %18\n\tv_floor_f32 %4, %4\n\tv_add_f32 %5, %5, %17\n\tv_mul_f32 %6, %6, %17\n\tv_fma_f32 %7, %7, %17, %18\n\tv_floor_f32 %0, %0\n\tv_add_f32 %1, %1, %17\n\tv_mul_f32 %2, %2, %17\n\tv_fma_f32 %3, %3, %17, %18\n\tv_floor_f32 %4, %4\n\tv_add_f32 %5, %5, %17\n\tv_mul_f32 %6, %6, %17\n\tv_fma_f32 %7, %7, %17, %18\n\tv_floor_f32 %0, %0\n\tv_add_f32 %1, %1, %17\n\tv_mul_f32 %2, %2, %17\n\tv_fma_f32 %3, %3, %17, %18\n\tv_floor_f32 %4, %4\n\tv_add_f32 %5, %5, %17\n\tv_mul_f32 %6, %6, %17\n\tv_fma_f32 %7, %7, %17, %18\n\tv_floor_f32 %0, %0\n\tv_add_f32 %1, %1, %17\n\tv_mul_f32 %2, %2, %17\n\tv_fma_f32 %3, %3, %17, %18\n\tv_floor_f32 %4, %4\n\tv_add_f32 %5, %5, %17\n\tv_mul_f32 %6, %6, %17\n\tv_fma_f32 %7, %7, %17, %18\n\tv_floor_f32 %0, %0\n\tv_add_f32 %1, %1, %17\n\tv_mul_f32 %2, %2, %17\n\tv_fma_f32 %3, %3, %17, %18\n\tv_floor_f32 %4, %4\n\tv_add_f32 %5, %5, %17\n\tv_mul_f32 %6, %6, %17\n\tv_fma_f32 %7, %7, %17, %18\n\tv_floor_f32 %0, %0\n\tv_add_f32 %1, %1, %17\n\tv_mul_f32 %2, %2, %17\n\tv_fma_f32 %3, %3, %17, %18\n\tv_floor_f32 %4, %4\n\tv_add_f32 %5, %5, %17\n\tv_mul_f32 %6, %6, %17\n\tv_fma_f32 %7, %7, %17, %18\n\tv_floor_f32 %0, %0\n\tv_add_f32 %1, %1, %17\n\tv_mul_f32 %2, %2, %17\n\tv_fma_f32 %3, %3, %17, %18\n\tv_floor_f32 %4, %4\n\tv_add_f32 %5, %5, %17\n\tv_mul_f32 %6, %6, %17\n\tv_fma_f32 %7, %7, %17, %18\n\tv_floor_f32 %0, %0\n\tv_add_f32 %1, %1, %17\n\tv_mul_f32 %2, %2, %17\n\tv_fma_f32 %3, %3, %17, %18\n\tv_floor_f32 %4, %4\n\tv_add_f32 %5, %5, %17\n\tv_mul_f32 %6, %6, %17\n\tv_fma_f32 %7, %7, %17, %18\n\t");
+        } else if (KIND == 106) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_add_f32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_add_f32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_add_f32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_add_f32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_add_f32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\t");
+        } else if (KIND == 107) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_fma_f32 %1, %1, %17, %18 clamp\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_fma_f32 %3, %3, %17, %18 clamp\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_fma_f32 %5, %5, %17, %18 clamp\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_fma_f32 %7, %7, %17, %18 clamp\n\t");
+        } else if (KIND == 108) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_f32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_f32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_f32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_f32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_f32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_f32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_f32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_f32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\t");
+        } else if (KIND == 109) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_u32 %4, %4, %18\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_u32 %7, %7, %18\n\tv_add_f32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_f32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_u32 %0, %0, %18\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_u32 %6, %6, %18\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_u32 %4, %4, %18\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_u32 %7, %7, %18\n\tv_add_f32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_f32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_add_u32 %0, %0, %18\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_u32 %6, %6, %18\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_u32 %4, %4, %18\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_u32 %7, %7, %18\n\tv_add_f32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_f32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\t");
+        } else if (KIND == 110) {
+            OPS("v_add_u32 %0, %0, %18\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_u32 %6, %6, %18\n\tv_add_f32 %7, %7, %17\n\tv_add_f32 %0, %0, %17\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_add_u32 %4, %4, %18\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_u32 %7, %7, %18\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_u32 %2, %2, %18\n\tv_add_f32 %3, %3, %17\n\tv_add_f32 %4, %4, %17\n\tv_add_u32 %5, %5, %18\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_add_u32 %0, %0, %18\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_u32 %6, %6, %18\n\tv_add_f32 %7, %7, %17\n\tv_add_f32 %0, %0, %17\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_add_u32 %4, %4, %18\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_u32 %7, %7, %18\n\tv_add_f32 %0, %0, %17\n\tv_add_f32 %1, %1, %17\n\tv_add_u32 %2, %2, %18\n\tv_add_f32 %3, %3, %17\n\tv_add_f32 %4, %4, %17\n\tv_add_u32 %5, %5, %18\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_add_u32 %0, %0, %18\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_u32 %6, %6, %18\n\tv_add_f32 %7, %7, %17\n\tv_add_f32 %0, %0, %17\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_add_u32 %4, %4, %18\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_u32 %7, %7, %18\n\t");
+        } else if (KIND == 111) {
+            OPS("v_xor_b32 %0, %0, %18\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_xor_b32 %4, %4, %18\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_xor_b32 %0, %0, %18\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_xor_b32 %4, %4, %18\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_xor_b32 %0, %0, %18\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_xor_b32 %4, %4, %18\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_xor_b32 %0, %0, %18\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_xor_b32 %4, %4, %18\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_xor_b32 %0, %0, %18\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_xor_b32 %4, %4, %18\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_xor_b32 %0, %0, %18\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_xor_b32 %4, %4, %18\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_xor_b32 %0, %0, %18\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_xor_b32 %4, %4, %18\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_xor_b32 %0, %0, %18\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_xor_b32 %4, %4, %18\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\t");
+        } else if (KIND == 112) {
+            OPS("v_mov_b32 %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_mov_b32 %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_mov_b32 %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_mov_b32 %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_mov_b32 %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_mov_b32 %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_mov_b32 %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_mov_b32 %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_mov_b32 %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_mov_b32 %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_mov_b32 %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_mov_b32 %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_mov_b32 %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_mov_b32 %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_mov_b32 %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_mov_b32 %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_mov_b32 %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_mov_b32 %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_mov_b32 %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_mov_b32 %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_mov_b32 %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_mov_b32 %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_mov_b32 %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_mov_b32 %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_mov_b32 %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_mov_b32 %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_mov_b32 %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_mov_b32 %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_mov_b32 %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_mov_b32 %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_mov_b32 %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_mov_b32 %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\t");
+        } else if (KIND == 113) {
+            OPS("v_lshrrev_b32 %0, 3, %0\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_lshrrev_b32 %2, 3, %2\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_lshrrev_b32 %4, 3, %4\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_lshrrev_b32 %6, 3, %6\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_lshrrev_b32 %0, 3, %0\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_lshrrev_b32 %2, 3, %2\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_lshrrev_b32 %4, 3, %4\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_lshrrev_b32 %6, 3, %6\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_lshrrev_b32 %0, 3, %0\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_lshrrev_b32 %2, 3, %2\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_lshrrev_b32 %4, 3, %4\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_lshrrev_b32 %6, 3, %6\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_lshrrev_b32 %0, 3, %0\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_lshrrev_b32 %2, 3, %2\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_lshrrev_b32 %4, 3, %4\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_lshrrev_b32 %6, 3, %6\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_lshrrev_b32 %0, 3, %0\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_lshrrev_b32 %2, 3, %2\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_lshrrev_b32 %4, 3, %4\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_lshrrev_b32 %6, 3, %6\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_lshrrev_b32 %0, 3, %0\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_lshrrev_b32 %2, 3, %2\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_lshrrev_b32 %4, 3, %4\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_lshrrev_b32 %6, 3, %6\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_lshrrev_b32 %0, 3, %0\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_lshrrev_b32 %2, 3, %2\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_lshrrev_b32 %4, 3, %4\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_lshrrev_b32 %6, 3, %6\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_lshrrev_b32 %0, 3, %0\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_lshrrev_b32 %2, 3, %2\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_lshrrev_b32 %4, 3, %4\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_lshrrev_b32 %6, 3, %6\n\tv_bfe_u32 %7, %7, %18, 7\n\t");
+        } else if (KIND == 114) {
+            OPS("v_and_b32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_and_b32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_and_b32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_and_b32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_and_b32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_and_b32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_and_b32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_and_b32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_and_b32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_and_b32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_and_b32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_and_b32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_and_b32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_and_b32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_and_b32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_and_b32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_and_b32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_and_b32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_and_b32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_and_b32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_and_b32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_and_b32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_and_b32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_and_b32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_and_b32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_and_b32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_and_b32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_and_b32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_and_b32 %0, %0, %17\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_and_b32 %2, %2, %17\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_and_b32 %4, %4, %17\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_and_b32 %6, %6, %17\n\tv_bfe_u32 %7, %7, %18, 7\n\t");
+        } else if (KIND == 115) {
+            unsigned long long sv;
+            asm volatile("s_mov_b64 %0, exec" : "=s"(sv));
+#define X(n) "v_cmpx_ge_u32 vcc, " R(n) ", %17\n\t"
+            OPS(BLOCK8x8(X));
+#undef X
+            asm volatile("s_mov_b64 exec, %0" : : "s"(sv));
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), q1 = __builtin_amdgcn_s_memrealtime();
@@ -431,8 +478,9 @@ static const char *kNames[] = {
     "v_min_i32", "v_not_b32", "v_fma_f32 (neg src)", "v_fmac_f32 (VOP2)", "v_alignbit_b32", "v_perm_b32", "v_cvt_f32_u32",
     "v_xad_u32", "v_add3_u32", "v_and_b32_sdwa", "v_mov_b32_dpp",
     "v_cndmask_b32_e64 (vcc as mask)", "v_cndmask_e32 vcc : v_add_u32 1:1", "v_cndmask_e32 vcc : v_add_u32 1:3", "v_cndmask sgpr : v_add_u32 1:1", "v_bfe_u32 : v_add_u32 1:1", "v_bfe_u32 : v_add_u32 1:3", "v_lshlrev_b32 (imm)", "v_lshrrev_b32 (reg)", "v_ashrrev_i32 (imm)", "v_and_b32", "v_or_b32", "v_sub_u32", "v_max_f32", "v_max_u32", "v_med3_f32", "v_cmp_lt_u32 -> vcc", "v_cmp_class_f32 -> vcc", "v_mul_lo_u32", "v_and_b32 + literal", "v_add_f32 (sgpr src)", "v_mul_f32 (inline const)", "v_xor_b32 (sgpr src)", "v_sub_f32_e64 abs/neg", "v_mul_f32 : v_bfe : v_cmp mix", "v_cvt_f32_ubyte0", "v_mbcnt_lo_u32_b32", "v_subrev_u32", "v_lshlrev_b32 (sgpr amount)", "v_mul_f32 (2 vgpr, distinct)", 
-    "indep: bfe,addu (S F)", "indep: bfe,addu,xor,addu (S F F F)", "indep: bfe,bfe,addu,addu (S S F F)", "indep: bfe,addf (S Ff)", "indep: bfe,mulf,addf,fma (S Ff Ff Ff)", "indep: mulf,bfe,addf,cmp", "indep: cmp,addf (S Ff)", "indep: cmp,addu (S F)", "indep: cvt,addf (S Ff)", "indep: minf,addf (S Ff)", "indep: lshl_or,addu,addu (S F F)", "indep: addu,addf (F Ff)", "indep: 7F 1S (addf x7, bfe)", "indep: 4F 4S blocks", "indep: 16F 16S blocks"};
-constexpr int kKinds = 95;
+    "indep: bfe,addu (S F)", "indep: bfe,addu,xor,addu (S F F F)", "indep: bfe,bfe,addu,addu (S S F F)", "indep: bfe,addf (S Ff)", "indep: bfe,mulf,addf,fma (S Ff Ff Ff)", "indep: mulf,bfe,addf,cmp", "indep: cmp,addf (S Ff)", "indep: cmp,addu (S F)", "indep: cvt,addf (S Ff)", "indep: minf,addf (S Ff)", "indep: lshl_or,addu,addu (S F F)", "indep: addu,addf (F Ff)", "indep: 7F 1S (addf x7, bfe)", "indep: 4F 4S blocks", "indep: 16F 16S blocks", 
+    "v_floor_f32", "v_ldexp_f32", "v_fract_f32", "v_trunc_f32", "v_rndne_f32", "v_mul_f32_e64 clamp", "v_fma_f32 clamp", "v_frexp_exp_i32_f32", "v_cvt_u32_f32", "v_mul_f32 literal", "indep: floor,addf,mulf,fma (S Ff Ff Ff)", "indep: bfe,addf,addf (S Ff Ff)", "indep: bfe,fma clamp (S Fc)", "indep: bfe,bfe,addf (S S Ff)", "indep: bfe,addu,addf (S I Ff)", "indep: addu,addf,addf (I Ff Ff)", "indep: xor,bfe,addf,addf (I S Ff Ff)", "indep: mov,bfe (I S)", "indep: lshrrev,bfe (I S)", "indep: and,bfe (I S)", "v_cmpx_ge_u32 (always true)"};
+constexpr int kKinds = 116;
 
 template <int K>
 void launch(int blocks, unsigned *out, unsigned long long *clk, int iters) {
