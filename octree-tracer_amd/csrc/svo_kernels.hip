@@ -21,16 +21,7 @@
 #include "svo_device.h"
 #include "svo_trace_fn.h"
 
-// Step variants kept for same-box A/B builds (-DSVO_STEP_...=1); the defaults are what measured fastest.
-#ifndef SVO_STEP_CENTRE
-#define SVO_STEP_CENTRE 1
-#endif
-#ifndef SVO_STEP_MASK
-#define SVO_STEP_MASK 1
-#endif
-#ifndef SVO_STEP_BOUNDS
-#define SVO_STEP_BOUNDS 0
-#endif
+// Build-time switches kept for same-box A/B builds (-DSVO_...=n); the defaults are what measured fastest.
 #ifndef SVO_WALK_STOP
 #define SVO_WALK_STOP 1
 #endif
@@ -506,7 +497,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : SVO_WAVES_PER_SIMD)
     float S0 = 1, S1 = 1, S2 = 1;     // copysign(1, dir): r_sign of shader.wgsl:211
     float dist = 0.0f, tcur = 0.0f;
     float stepsf = 0.0f;              // steps taken (shader.wgsl:240), an integer 0 .. 101
-    float nmf = 7.0f;                 // axes NOT in the last step's mask: bit i = t_i differed from the minimum (7: no step taken yet)
+    float nmf = 0.0f;                 // the last step's mask (axes whose t_i was the minimum) as a number 0 .. 7, times kNudge
     uint32_t mu0 = __float_as_uint(kMagic), mu1 = mu0, mu2 = mu0;  // path codes, as the bits of kMagic + code
     // sh: at a leaf, the bit of the path codes that selects the child at the leaf's level, D - L (the leaf's cell is 2^sh grid
     // units wide); before a walk, one more than the bit of the first level to read.  nidx: the child group that level lives in.
@@ -548,7 +539,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : SVO_WAVES_PER_SIMD)
         const bool too_deep = leaf_w < (kVoxelOffset << 4), solid = (leaf_w >> 4) != kVoxelOffset, inb = steps == 101u;
         const bool stop_here = too_deep || solid;
         if (too_deep) atomicOr(a.status, 1u);  // reported by svo_sync
-        const uint32_t L = (uint32_t)D - sh, nm = 7u - (uint32_t)nmf;
+        const uint32_t L = (uint32_t)D - sh, nm = (uint32_t)__builtin_fmaf(nmf, 1.0f / kNudge, 0.5f);  // (nmf is 0 .. 7 times k, up to rounding)
         uint32_t c0n = (Dr0 > 0.0f) ? 2u : 1u, c1n = (Dr1 > 0.0f) ? 2u : 1u, c2n = (Dr2 > 0.0f) ? 2u : 1u;
         uint32_t ncode = ((nm & 1u) ? c0n : 0u) | ((nm & 2u) ? (c1n << 2) : 0u) | ((nm & 4u) ? (c2n << 4) : 0u);
         if (steps == 0u) ncode = out >> 26;               // no step taken: the entry normal
@@ -593,7 +584,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : SVO_WAVES_PER_SIMD)
                 dist = d2;
                 tcur = 0.0f;
                 stepsf = 0.0f;
-                nmf = 7.0f;
+                nmf = 0.0f;
                 const uint32_t ecode = normal_code(truncf(pos2[0] * 1.000001f)) | (normal_code(truncf(pos2[1] * 1.000001f)) << 2) |
                                        (normal_code(truncf(pos2[2] * 1.000001f)) << 4);
                 out = (out & 0x03FFFFFFu) | (ecode << 26);
@@ -865,7 +856,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : SVO_WAVES_PER_SIMD)
                         mu2 = entry_magic<GE>(P2);
                         tcur = 0.0f;
                         stepsf = 0.0f;
-                        nmf = 7.0f;
+                        nmf = 0.0f;
                         if (CAM && cam_ok && dist == 0.0f) {
                             // a ray from the camera's own position: the walk the wave made at the start (see above)
                             const uint32_t sh0 = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 2), L0 = (uint32_t)D - sh0;
@@ -970,60 +961,40 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : SVO_WAVES_PER_SIMD)
                 stf *= 0.5f;  // ST_LEAF -> ST_PENDING
             } else {
                 const float Hm = __builtin_amdgcn_ldexpf(0.5f, (int)sh);     // 2^(sh-1) = voxel_size / 2 in grid units (sh = D - L >= 1)
-                const float hmh = Hm - 0.5f, hbig = Hm * 25165824.0f, hc = Hm - kScale;  // (3 * 2^23 * Hm = 1.5 * 2^(23+sh): ulp 2^sh)
-                // leaf centre along one axis and a = (centre - pos) + r_sign * voxel_size / 2 (shader.wgsl:229): U - (h - 1/2) is exact
-                // and never halfway between two multiples of 2^sh, so adding and subtracting hbig rounds it to the leaf's lower
-                // corner floor(U / 2^sh) 2^sh; + (h - 2^22) makes that the centre, exactly (the reference sums +-2^-k: exact too)
-#if SVO_STEP_CENTRE == 1
-                // (variant: the lower corner by masking the code's low bits -- one and-or of the other instruction group per axis)
+                // leaf centre along one axis and a = (centre - pos) + r_sign * voxel_size / 2 (shader.wgsl:229): the code with its low sh
+                // bits replaced by 1 0 .. 0 is, read as a float, 2^23 + (lower corner + 2^(sh-1)); minus (2^23 + 2^22) that is the centre in
+                // grid units, exactly (the reference sums +-2^-k, which is exact too).  One instruction of the 4-cycle group per axis;
+                // the all-f32 form -- floor taken by the rounding of (U - (2^(sh-1) - 1/2)) + 3 * 2^(22+sh) -- costs four more of the
+                // other group and measured 2 % slower (profiles/r04_step_variants_ab.log)
                 const uint32_t keepm = 0xFFFFFFFFu << sh, hbit = __float_as_uint(kMagic + Hm);
                 auto t_axis = [&](uint32_t mu, float P, float Dr, float Y, float S) -> float {
                     const float c = __uint_as_float((mu & keepm) | hbit) - (kMagic + kScale);
                     return div_by_recip(__builtin_fmaf(S, Hm, c - P), Dr, Y);
                 };
-                (void)hmh; (void)hbig; (void)hc;
-#else
-                auto t_axis = [&](uint32_t mu, float P, float Dr, float Y, float S) -> float {
-                    const float g = (__uint_as_float(mu) - kMagic) - hmh;
-                    const float c = ((g + hbig) - hbig) + hc;
-                    return div_by_recip(__builtin_fmaf(S, Hm, c - P), Dr, Y);
-                };
-#endif
                 const float t0 = t_axis(mu0, P0, Dr0, Y0, S0), t1 = t_axis(mu1, P1, Dr1, Y1, S1), t2 = t_axis(mu2, P2, Dr2, Y2, S2);
                 // no NaNs here, so IEEE minNum equals the oracle's (b < a) ? b : a up to the sign of a zero, which no later value
                 // depends on, and "t_i <= min(t_j, t_k)" is "t_i equals the minimum of the three"
                 const float tnew = __builtin_fminf(__builtin_fminf(t0, t1), t2);
-                // f_i = 0 where t_i is that minimum, else 1: the difference is 0 or at least 2^-149, and 2^126 * 2^24 saturates it
-                auto differs = [&](float t) -> float {
-                    const float e = __builtin_amdgcn_fmed3f((t - tnew) * 8.5070592e37f, 0.0f, 1.0f);  // (clamp modifier; 2^126)
-                    return __builtin_amdgcn_fmed3f(e * 16777216.0f, 0.0f, 1.0f);
-                };
-#if SVO_STEP_MASK == 1
-                const float f0 = t0 == tnew ? 0.0f : 1.0f, f1 = t1 == tnew ? 0.0f : 1.0f, f2 = t2 == tnew ? 0.0f : 1.0f;
-                (void)differs;
-#else
-                const float f0 = differs(t0), f1 = differs(t1), f2 = differs(t2);
-#endif
-                // voxel_pos = pos + dir * t - normal * 2e-6, normal = mask * -sign(dir): k or 0, times the sign, in one fma
-                const float G0 = __builtin_fmaf(__builtin_fmaf(-kNudge, f0, kNudge), S0, P0 + Dr0 * tnew);
-                const float G1 = __builtin_fmaf(__builtin_fmaf(-kNudge, f1, kNudge), S1, P1 + Dr1 * tnew);
-                const float G2 = __builtin_fmaf(__builtin_fmaf(-kNudge, f2, kNudge), S2, P2 + Dr2 * tnew);
+                // voxel_pos = pos + dir * t - normal * 2e-6, normal = mask * -sign(dir): k where t_i is the minimum, else 0, times the
+                // sign, in one fma.  (The mask as 1 - clamp(clamp((t_i - min) 2^126) 2^24) needs no compare; same time, three more
+                // instructions.)
+                const float k0 = t0 == tnew ? kNudge : 0.0f, k1 = t1 == tnew ? kNudge : 0.0f, k2 = t2 == tnew ? kNudge : 0.0f;
+                const float G0 = __builtin_fmaf(k0, S0, P0 + Dr0 * tnew);
+                const float G1 = __builtin_fmaf(k1, S1, P1 + Dr1 * tnew);
+                const float G2 = __builtin_fmaf(k2, S2, P2 + Dr2 * tnew);
                 // in_bounds (shader.wgsl:177-180), -2^22 <= G < 2^22: G is a float, so below the bound it is at most 2^22 - 1/4 and
                 // 4 (2^22 - G) >= 1, at or above it <= 0; likewise 2 G + (2^23 + 1) >= 1 from -2^22 up and <= 0 from -2^22 - 1/2 down
+                // (six clamps and five products of the 2-cycle group; max3 / min3 first: three instructions fewer, not faster)
                 auto inside = [&](float G) -> float {
                     return __builtin_amdgcn_fmed3f(__builtin_fmaf(G, -4.0f, 4.0f * kScale), 0.0f, 1.0f) *
                            __builtin_amdgcn_fmed3f(__builtin_fmaf(G, 2.0f, 2.0f * kScale + 1.0f), 0.0f, 1.0f);
                 };
-#if SVO_STEP_BOUNDS == 1
-                const float inbf = inside(__builtin_fmaxf(__builtin_fmaxf(G0, G1), G2)) * inside(__builtin_fminf(__builtin_fminf(G0, G1), G2));
-#else
                 const float inbf = (inside(G0) * inside(G1)) * inside(G2);
-#endif
                 // the ray goes on unless the step leaves the cube or the count after it exceeds 100 (iff it is 100 now)
                 const float contf = inbf * __builtin_amdgcn_fmed3f(100.0f - stepsf, 0.0f, 1.0f);
                 tcur = tnew;
                 stepsf += inbf;                                          // (shader.wgsl:237-240: counted only inside the cube)
-                nmf = __builtin_fmaf(f2, 4.0f, __builtin_fmaf(f1, 2.0f, f0));
+                nmf = __builtin_fmaf(k2, 4.0f, __builtin_fmaf(k1, 2.0f, k0));  // k * (mask as a number 0 .. 7), decoded when the record is written
                 stf *= __builtin_fmaf(contf, 1.5f, 0.5f);                // ST_LEAF -> ST_DESC (goes on) or ST_PENDING (ended)
                 if (contf > 0.5f) {
                     // new path codes: the position is inside the cube.  `>` mode: ceil(G) - 1 + 2^22 = (2^22 - 1) - floor(-G), which

@@ -41,17 +41,17 @@ __device__ __forceinline__ void mat_vec(const float *m, float x, float y, float 
     for (int r = 0; r < 4; r++) out[r] = ((m[r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w;
 }
 
-// Ray generation, shader.wgsl:54-59,253-259
-__device__ __forceinline__ RayIn gen_ray(const svo_uniforms &u, uint32_t px, uint32_t py) {
+// Ray generation, shader.wgsl:54-59,253-259 (inv: camera_inverse, column-major; dim: the frame's width and height)
+__device__ __forceinline__ RayIn gen_ray_from(const float *inv, float dim_x, float dim_y, uint32_t px, uint32_t py) {
     float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-    float cx = fx / u.dimensions[0] * 2.0f;
-    float cy = fy / u.dimensions[1] * 2.0f;
+    float cx = fx / dim_x * 2.0f;
+    float cy = fy / dim_y * 2.0f;
     cx = cx - 1.0f;
     cy = cy - 1.0f;
     cy = cy * -1.0f;
     float p4[4], d4[4];
-    mat_vec(u.camera_inverse, 0.0f, 0.0f, 0.0f, 1.0f, p4);
-    mat_vec(u.camera_inverse, cx, cy, 1.0f, 1.0f, d4);
+    mat_vec(inv, 0.0f, 0.0f, 0.0f, 1.0f, p4);
+    mat_vec(inv, cx, cy, 1.0f, 1.0f, d4);
     RayIn r;
     r.px = p4[0] / p4[3];
     r.py = p4[1] / p4[3];
@@ -62,6 +62,9 @@ __device__ __forceinline__ RayIn gen_ray(const svo_uniforms &u, uint32_t px, uin
     r.dy = dy / len;
     r.dz = dz / len;
     return r;
+}
+__device__ __forceinline__ RayIn gen_ray(const svo_uniforms &u, uint32_t px, uint32_t py) {
+    return gen_ray_from(u.camera_inverse, u.dimensions[0], u.dimensions[1], px, py);
 }
 
 // in_bounds, shader.wgsl:177-180
