@@ -12,8 +12,10 @@ Workload (BASELINE.json metric "Mrays/sec at 1920x1080, depth-16 SVO"): determin
 max depth 16, ~107 M words (428 MB, larger than the 256 MiB Infinity Cache, under the 2^27-word
 layout cap), camera standing on the terrain, 1920x1080 primary rays, static tree
 (pause_adaptive), no shadows.  Data is synthetic (seeded generator, no reference counterpart).
-Beside the headline the line carries, measured in the same run outside the timed region: the first frame
-of a layout (no strip schedule yet), a moving camera, and the 4K frame of the same scene (config.also).
+The headline is that 1080p frame for EVERY N (an N-GPU headline on another frame is not comparable with the
+1-GPU line).  Beside it the line carries, measured in the same run outside the timed region: the first frame of a layout (no
+strip schedule yet), a moving camera, and the 4K frame of the same scene -- the frame BASELINE.json's 1 -> 8 GPU target refers
+to -- under config.also; for N > 1 both frames come with the colour wire, the one-GPU rate and the link bound.
 """
 import argparse
 import json
@@ -30,10 +32,13 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-# vector-instruction issue peak: 256 CUs x 4 SIMDs x one wave64 instruction per cycle at 2.4 GHz -- the rate measured for
-# full-rate instructions (v_add_u32, v_xor, v_fma_f32: 0.9-1.2 SIMD cycles each with 8 waves per SIMD; the half-rate group --
-# v_bfe, v_lshl_or, v_and_or, v_bfi, v_min3, conversions -- takes 1.7-2.1): tools/instr_cost.hip, profiles/r02_instr_cost.log
-VALU_PEAK_GINSTR_S = 256 * 4 * 2.4
+# vector-instruction issue peak (round 4, by wall clock: tools/issue_rate.hip, profiles/r04_issue_rate*.log; the microarch guide says
+# the same): a SIMD issues a wave64 instruction of the fast group -- v_add / v_mul / v_fma_f32, v_add_u32, v_and / v_or / v_xor,
+# right shifts, v_mov -- every 2 cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 2.  Everything else (compares, selects, min / max, conversions,
+# v_bfe, shift-or and other three-operand integer forms, left shifts) takes 4 cycles, but an f32 instruction of the fast group
+# issues beside one of those for nothing.  (Round 2's 1-instruction-per-cycle peak came from s_memtime deltas of a loop whose
+# scalar overhead was left out)
+VALU_PEAK_GINSTR_S = 256 * 4 * 2.4 / 2
 
 WORKLOADS = {
     # name: (width, height, scene kwargs)
@@ -53,6 +58,20 @@ def free_port():
         return sock.getsockname()[1]
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited"""
+    try:
+        t = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if t[0] == "max" else float(t[0]) / float(t[1])
+    except (OSError, ValueError, IndexError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        return None if q < 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+    except (OSError, ValueError):
+        return None
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (torch.distributed.run) before
     anything here has touched the GPU, relay what it prints and exit with its code."""
@@ -70,9 +89,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: terrain16_1080p (BASELINE.json's metric) on one GPU; terrain16_4k on several -- the frame the "
-                         "1 -> 8 GPU target of BASELINE.json refers to (the 1080p frame of the same scene is then under config.also)")
+    ap.add_argument("--workload", default="terrain16_1080p", choices=sorted(WORKLOADS),
+                    help="default: terrain16_1080p, the frame BASELINE.json's metric is quoted on, for every N; the 4K frame of the same "
+                         "scene -- the one the 1 -> 8 GPU target refers to -- is measured beside it (config.also)")
     ap.add_argument("--tile-w", type=int, default=64)
     ap.add_argument("--tile-h", type=int, default=8)
     ap.add_argument("--preroll", type=int, default=120,
@@ -123,8 +142,6 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     pipelined = world > 1 or a.force_pipeline
-    if a.workload is None:
-        a.workload = "terrain16_4k" if world > 1 else "terrain16_1080p"
     if pipelined:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:  # only the single-process validation mode gets here without a launcher
@@ -338,37 +355,47 @@ def main():
         if ALGO_BYTES_PER_RAY.get(other) and not pipelined:
             extras["also"]["roofline_frac"] = round(ALGO_BYTES_PER_RAY[other] * ow["width"] * ow["height"] / (float(np.mean(k2)) * 1e-3) / 1e9
                                                     / HBM_PEAK_GBS, 5)
-        if pipelined and not colour_wire:
-            # (4) the same sharded frame with the COLOUR wire: the ranks shade their own tiles and the RGBA8 image -- what the
-            # reference displays (shader.wgsl:261-304, render.rs:246-248) -- is what travels: 4 bytes per ray instead of 12
-            e3, k3, out3 = measure(W, H, k_extra, 3, "rgba8")
-            gpu.sync()
-            frame_rgba = out3.reshape(-1, 1).cpu().numpy().view(np.uint32) if rank == 0 else None
-            extras["also_rgba8"] = {"workload": a.workload, "wire": "rgba8: 4 B/ray (shaded RGBA8 colour; records stay on the ranks)",
-                                    "value": round(n_rays * k_extra / e3 / 1e6, 2), "unit": "Mrays/s", "steps": k_extra,
-                                    "ms_per_step": round(e3 / k_extra * 1e3, 4), "kernel_avg_ms": round(float(np.mean(k3)), 4)}
-        if pipelined:
-            # (5) one GPU, the same frame, unsharded and serial (rank 0 alone, the others wait): what N GPUs are compared with
+
+        def sharded_extras(Wx, Hx, name, keep_frame):
+            """N > 1, one frame size: (4) the same sharded frame with the COLOUR wire -- the ranks shade their own tiles and the RGBA8
+            image, what the reference displays (shader.wgsl:261-304, render.rs:246-248), is what travels: 4 bytes per ray instead
+            of 12; (5) one GPU, the same frame, unsharded and serial (rank 0 alone, the others wait): what N GPUs are compared with;
+            (6) what the links allow: every ray's wire bytes end on rank 0, (N - 1) / N of them over rank 0's N - 1 inbound xGMI links,
+            one peer per link (7 links per GPU, ~64 GB/s per link and direction sustained: DESIGN.md 7)"""
+            nonlocal frame_rgba
+            nx = Wx * Hx
+            res = {}
+            if not colour_wire:
+                e3, k3, out3 = measure(Wx, Hx, k_extra, 3, "rgba8")
+                gpu.sync()
+                if keep_frame:
+                    frame_rgba = out3.reshape(-1, 1).cpu().numpy().view(np.uint32) if rank == 0 else None
+                res["also_rgba8"] = {"workload": name, "wire": "rgba8: 4 B/ray (shaded RGBA8 colour; records stay on the ranks)",
+                                     "value": round(nx * k_extra / e3 / 1e6, 2), "unit": "Mrays/s", "steps": k_extra,
+                                     "ms_per_step": round(e3 / k_extra * 1e3, 4), "kernel_avg_ms": round(float(np.mean(k3)), 4)}
             if rank == 0:
                 try:  # (rank 0 only, no collective inside: a failure here must not keep the other ranks waiting at the barrier below)
-                    e1, k1, _ = measure(W, H, k_extra, 3, a.wire, serial_one_gpu=True)
-                    extras["one_gpu_same_workload"] = {"value": round(n_rays * k_extra / e1 / 1e6, 2), "unit": "Mrays/s", "steps": k_extra,
-                                                       "ms_per_step": round(e1 / k_extra * 1e3, 4), "kernel_avg_ms": round(float(np.mean(k1)), 4),
-                                                       "what": "rank 0 traces the whole frame alone, frames serial, same run"}
+                    e1, k1, _ = measure(Wx, Hx, k_extra, 3, a.wire, serial_one_gpu=True)
+                    res["one_gpu_same_workload"] = {"value": round(nx * k_extra / e1 / 1e6, 2), "unit": "Mrays/s", "steps": k_extra,
+                                                    "ms_per_step": round(e1 / k_extra * 1e3, 4), "kernel_avg_ms": round(float(np.mean(k1)), 4),
+                                                    "what": "rank 0 traces the whole frame alone, frames serial, same run"}
                 except Exception as ex:  # noqa: BLE001
-                    extras["one_gpu_same_workload"] = {"error": repr(ex)}
+                    res["one_gpu_same_workload"] = {"error": repr(ex)}
             barrier()
-            # (6) what the links allow: every ray's wire bytes end on rank 0, (N - 1) / N of them over rank 0's N - 1 inbound
-            # xGMI links, one peer per link (7 links per GPU, ~64 GB/s per link and direction sustained: DESIGN.md 7)
             link_gbs = 64.0
             bound = {}
             for wname, bpr in (("packed12", 12), ("full16", 16), ("rgba8", 4)):
-                per_link = n_rays * bpr / world  # bytes one peer sends per frame
-                bound[wname] = {"bytes_into_rank0_per_frame": int(n_rays * bpr * (world - 1) // world), "bytes_per_link_per_frame": int(per_link),
+                per_link = nx * bpr / world  # bytes one peer sends per frame
+                bound[wname] = {"bytes_into_rank0_per_frame": int(nx * bpr * (world - 1) // world), "bytes_per_link_per_frame": int(per_link),
                                 "min_ms_per_frame": round(per_link / (link_gbs * 1e9) * 1e3, 4),
-                                "max_mrays_s": round(n_rays / (per_link / (link_gbs * 1e9)) / 1e6, 1)}
-            extras["link_bound"] = {"assumed_gb_s_per_link_and_direction": link_gbs, "links_into_rank0": world - 1, **bound,
-                                    "note": "an upper bound at perfect link efficiency; the gathers of consecutive frames overlap the traces"}
+                                "max_mrays_s": round(nx / (per_link / (link_gbs * 1e9)) / 1e6, 1)}
+            res["link_bound"] = {"assumed_gb_s_per_link_and_direction": link_gbs, "links_into_rank0": world - 1, **bound,
+                                 "note": "an upper bound at perfect link efficiency; the gathers of consecutive frames overlap the traces"}
+            return res
+
+        if pipelined:
+            extras.update(sharded_extras(W, H, a.workload, True))                        # the headline frame
+            extras["also"].update(sharded_extras(ow["width"], ow["height"], other, False))  # the other frame (4K: the scaling target's)
         for _, r, _ in lanes:
             r.resize((W, H))
             r.update(pkg.Settings(fov=90.0), pkg.Character(cam, look))
@@ -412,7 +439,11 @@ def main():
                 getattr(u, f)[:] = list(getattr(render.uniforms, f))
             u.flags, u.misc_value = render.uniforms.flags, render.uniforms.misc_value
             host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            cores = max(1, min(host_cores, 256))  # every host core this process may use (the oracle's pool takes up to 256 threads)
+            # every host core this process may USE: the affinity mask says 256 on the GPU box, its cgroup quota 16 CPUs -- and past the
+            # quota more threads only get throttled (tools/cpu_scaling_probe.py, profiles/r04_cpu_scaling.log: 3.8 / 7.6 / 8.4 / 7.3 / 6.8
+            # Mrays/s with 8 / 16 / 32 / 64 / 256 threads; round 3's 256-thread figure was the slow end of that curve)
+            quota = cgroup_cpu_quota()
+            cores = max(1, min(host_cores, 256, int(math.ceil(quota)) if quota else 256))
             # bounded sample: the top H / cpu_frac rows... a full frame is only seconds of CPU work, so by
             # default (cpu_frac = 1) the sample is the whole frame and the byte count below is exact
             rows = H // a.cpu_frac
@@ -445,20 +476,23 @@ def main():
                 got8 = frame_rgba.reshape(H, W)[:rows].reshape(-1).view(np.uint8).reshape(-1, 4).astype(np.int32)
                 result["config"]["also_rgba8"]["image_matches_oracle_fs_main_within_1_code_value"] = bool(np.abs(got8 - want8).max() <= 1)
             cpu = {"value": round(len(rec) * reps / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores,
-                   "host_cores_available": host_cores, "host_cores_total": os.cpu_count(), "kind": "port",
+                   "host_cores_available": host_cores, "host_cores_total": os.cpu_count(), "cgroup_cpu_quota": quota, "kind": "port",
                    "sample": f"rows 0..{rows - 1} of the same frame ({len(rec)} rays) traced {reps} times ({cpu_s:.1f} s), "
-                             f"oracle/svo_oracle.c (restart-from-root algorithm of shader.wgsl), {cores} pthreads",
+                             f"oracle/svo_oracle.c (restart-from-root algorithm of shader.wgsl), {cores} pthreads (persistent pool, "
+                             "256-pixel spans from an atomic cursor)",
                    "sample_algo_bytes_per_ray": round(sample_bpr, 3), "w_restart_words_per_ray": round(float(st[:, 0].mean()), 2),
                    "gpu_frame_matches_oracle_on_sample": parity}
         if bytes_per_ray is not None:
             achieved = bytes_per_ray * rays_per_launch / (kernel_avg_ms * 1e-3) / 1e9
-            traffic = valu = None
+            traffic = valu = salu = None
+            tj = {}
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if tj.get("workload") == a.workload and world == 1:
                     traffic = tj.get("hbm_bytes_per_launch")
                     valu = tj.get("valu_wave_instructions_per_launch")
+                    salu = tj.get("salu_wave_instructions_per_launch")
             # `bound` names the contractual ceiling (BASELINE.json: fraction of the HBM-read roofline on ALGORITHMIC bytes); what
             # the frame time actually follows is a balance of instruction issue and dependent-load latency: memory-side traffic is
             # a fraction of the algorithmic bytes (L2 absorbs the shared ancestors), see roofline_valu and DESIGN.md 4.8 / 6
@@ -467,18 +501,24 @@ def main():
                                   "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (not this run)",
                                   "achieved_algorithmic_gbs": round(achieved, 2),
                                   "measured_hbm_gbs": round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 2) if traffic else None,
-                                  "measured_limiter": "no single resource: instruction issue and dependent-load latency in balance (same-box A/Bs, "
-                                                      "profiles/r03_sensitivity_ab.log: +10 % vector instructions -> +3..4 % time, twice the loads -> +5 %, "
-                                                      "a seventh wave per SIMD -> +3 %); not HBM bandwidth",
+                                  "measured_limiter": "not HBM bandwidth: the latency of the walk's dependent loads (half of a wave's time; L1 misses of a "
+                                                      "69 % of wave-loads) against seven waves per SIMD, and the issue of the 4-cycle instruction group "
+                                                      "(DESIGN.md 4.9, 6; profiles/r04_*)",
                                   "kernel": "trace_stack_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4),
                                   "algo_bytes_per_ray": round(bytes_per_ray, 3), "rays_per_launch": rays_per_launch}
             if valu:
                 ach = valu / (kernel_avg_ms * 1e-3) / 1e9
+                salu_ps = (salu / (kernel_avg_ms * 1e-3) / 1e9) if salu else None
                 result["roofline_valu"] = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s",
                                            "frac": round(ach / VALU_PEAK_GINSTR_S, 4), "instructions_per_launch": valu,
-                                           "source": "profiles/traffic.json: SQ_INSTS_VALU of this workload's launch (rocprofv3 --pmc pass, not this run); "
-                                                     "peak = 1024 SIMDs x 1 full-rate wave64 instruction per cycle x 2.4 GHz (profiles/r02_instr_cost.log; "
-                                                     "about half of this kernel's vector instructions are half-rate ones)"}
+                                           "salu_instructions_per_launch": salu, "salu_g_instr_s": round(salu_ps, 1) if salu_ps else None,
+                                           "slow_group_share_static": tj.get("valu_slow_group_share_static"),
+                                           "source": "profiles/traffic.json: SQ_INSTS_VALU / SQ_INSTS_SALU of this workload's launch (rocprofv3 --pmc passes, not this "
+                                                     "run); peak = 1024 SIMDs x one wave64 instruction of the 2-cycle group per 2 cycles x 2.4 GHz "
+                                                     "(tools/issue_rate.hip by wall clock, profiles/r04_issue_rate.log; MI355X_MICROARCH.md: v_fma_f32 2 cycles). "
+                                                     "frac is a LOWER bound of how busy the issue port is: instructions of the 4-cycle group count as one here "
+                                                     "(slow_group_share_static: their share in the hot loop's ISA, profiles/r04_hot_loop_isa_table.md), while f32 "
+                                                     "instructions issued beside them cost nothing"}
         if cpu is not None:
             result["cpu_baseline"] = cpu
         print(json.dumps(result), flush=True)

@@ -105,7 +105,8 @@ typedef enum svo_option {
                                 the same layout first, rebuilding that schedule every n frames; 0: screen order.
                                 Results do not depend on it. */
     SVO_OPT_TREE_DEPTH = 9,  /* upper bound of the octree depth (Settings.octree_depth, app.rs:24); default 16.
-                                <= 16: default kernel; <= 23: deep-stack kernel; above: the general RESTART kernel */
+                                <= 16: default kernel; <= 22: deep-stack kernel (the STACK variant's 23-bit path codes resolve 22 levels; it was 23 up to
+                                round 3); above: the general RESTART kernel */
     SVO_OPT_BLOCK_SHAPE = 10, /* log2 of the width of the 64-pixel blocks a wave works on (3: 8x8, 4: 16x4, ...) */
     SVO_OPT_DEBUG_BUFFER = 7, /* device pointer receiving 16 words per wave: start, queue-dry, end (10 ns ticks), rounds, ...,
                                  shader cycles per phase (refill, descent, step), descent-loop shape (tools/wave_timeline.py) */

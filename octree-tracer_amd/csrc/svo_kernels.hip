@@ -28,6 +28,9 @@
 #ifndef SVO_TOP_IN_LDS   // 0: the top table is read from global memory (2 KiB less LDS per workgroup)
 #define SVO_TOP_IN_LDS 1
 #endif
+#ifndef SVO_WAVES_PER_SIMD_CNT   // of the counting instantiations (hit counters live)
+#define SVO_WAVES_PER_SIMD_CNT 6
+#endif
 #ifndef SVO_WAVES_PER_SIMD   // of the default instantiation (static tree, trees up to depth 16)
 #define SVO_WAVES_PER_SIMD 7
 #endif
@@ -280,7 +283,7 @@ __device__ __forceinline__ const TraceArgs &fresh_args() {
 
 // CNT: hit counters live (adaptive mode, shader.wgsl:157-161), see step 3a in the loop.
 template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD>
-__global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : SVO_WAVES_PER_SIMD)) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
+__global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT : ((SHD || DBG) ? 6 : SVO_WAVES_PER_SIMD))) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : SVO_WAVES_PER_SIMD)
     // hundreds of later visits of a word near the root cost one LDS read each, on whichever lane and ray they happen.
     uint32_t *cq = pool_all + (BLOCK / 64) * (kPoolWords * 64) + (tid >> 6) * kCountQueue;  // (CNT only: the launch allocates both)
     uint32_t *sat_tags = pool_all + (BLOCK / 64) * (kPoolWords * 64) + (BLOCK / 64) * kCountQueue;
-    auto sat_slot = [](uint32_t p) -> uint32_t { return (p ^ (p >> 9)) & 511u; };  // kSatTags = 512 (no multiply: quarter rate)
+    auto sat_slot = [](uint32_t p) -> uint32_t { return (p ^ (p >> 9)) & (uint32_t)(kSatTags - 1); };  // (no multiply: quarter rate)
     // ... and what the table said about the words of levels 1..K -- which the walk never reads -- is kept per level-K cell (4 bits
     // each: bit l = the level-l word on the way to this cell is saturated): every ray picked up and every ray that crosses a
     // level-K boundary would otherwise look those words up one level per loop iteration (half of the loop's iterations), and a
@@ -389,6 +392,9 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? 5 : SVO_WAVES_PER_SIMD)
         };
         uint32_t slot0, slot1;
         const bool i0 = merge_in(v0, rec0, slot0), i1 = merge_in(v1, rec1, slot1);
+        // (every lane's merges are done before any lane reads an entry back: the retry loops above diverge -- ADVICE r3)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const uint32_t p0 = rec0 & kWord, p1 = rec1 & kWord;
         const uint32_t n0 = (i0 && slot0 != 0xFFFFFFFFu) ? cq[slot0] >> 27 : rec0 >> 27;
         const uint32_t n1 = (i1 && slot1 != 0xFFFFFFFFu) ? cq[slot1] >> 27 : rec1 >> 27;
@@ -1288,7 +1294,7 @@ __global__ __launch_bounds__(kOrderThreads) void strip_order_kernel(const uint8_
         }
         if (blockIdx.x == 0) sched[tid] = acc;
     }
-    // each wave owns a contiguous run of 64-strip groups of the chunk; lanes 0..15 keep the class tallies
+    // each wave owns a contiguous run of 64-strip groups of the chunk; lanes 0..31 keep the class tallies
     const uint32_t chunk = order_chunk(n_strips);
     const uint32_t clo = min(blockIdx.x * chunk, n_strips), chi = min(clo + chunk, n_strips);
     const uint32_t per_wave = (((chunk / 64u) + kWaves - 1) / kWaves) * 64u;

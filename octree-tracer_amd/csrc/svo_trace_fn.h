@@ -334,6 +334,10 @@ constexpr float ST_IDLE = 0.0f, ST_PENDING = 1.0f, ST_LEAF = 2.0f, ST_DESC = 4.0
 // 22 KiB of LDS, i.e. 7 workgroups per CU.)
 constexpr int kPoolWords = 8;
 constexpr int kCountQueue = 128;  // CNT: queued (word, visits) pairs per wave
-constexpr int kSatTags = 512;     // CNT: words known to be saturated, direct-mapped, per workgroup
+#ifndef SVO_SAT_TAGS
+#define SVO_SAT_TAGS 256
+#endif
+constexpr int kSatTags = SVO_SAT_TAGS;  // CNT: words known to be saturated, direct-mapped, per workgroup (256: the counting workgroup stays at
+                                        // 26 KiB of LDS, six per CU; 512 entries measured the same time at five)
 
 }  // namespace svo

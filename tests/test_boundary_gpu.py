@@ -162,25 +162,28 @@ def test_bench_starts_its_own_ranks(pkg, gpu):
     assert line["n_gpus"] == 2 and line["steps"] == 4
     assert line["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] is True
     assert line["config"]["backend"] == "gloo"
-    assert line["config"]["workload"] == "terrain16_4k", "several GPUs: the frame the 1 -> 8 GPU target refers to is the default"
+    assert line["config"]["workload"] == "terrain16_1080p", "the headline is BASELINE.json's 1080p frame for every N (ADVICE r3)"
 
 
 def test_bench_multi_gpu_line_carries_both_wires(pkg, gpu):
-    """the N > 1 line evidences the scaling target in one run -- the 4K frame with the record wire as the
-    headline, the same frame with the colour wire beside it (checked against the oracle's fs_main), the one-GPU rate of the
-    same frame, and what rank 0's inbound links allow."""
+    """VERDICT r2 next 4 / ADVICE r3: the N > 1 line evidences the scaling target in one run -- BASELINE.json's 1080p frame with
+    the record wire as the headline (the same frame as the 1-GPU line), the colour wire beside it (checked against the oracle's
+    fs_main), the one-GPU rate of the same frame and what rank 0's inbound links allow; and all of that once more for the 4K
+    frame the 1 -> 8 GPU target refers to, under config.also."""
     line = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1"])
     cfg = line["config"]
-    assert line["n_gpus"] == 2 and cfg["workload"] == "terrain16_4k" and cfg["width"] == 3840
+    assert line["n_gpus"] == 2 and cfg["workload"] == "terrain16_1080p" and cfg["width"] == 1920 and "1920x1080" in line["metric"]
     assert "12 B/ray" in cfg["sharding"]
     assert line["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] is True
     also = cfg["also_rgba8"]
     assert also["value"] > 0 and also["image_matches_oracle_fs_main_within_1_code_value"] is True
     assert cfg["one_gpu_same_workload"]["value"] > 0
     lb = cfg["link_bound"]
-    assert lb["links_into_rank0"] == 1 and lb["packed12"]["bytes_into_rank0_per_frame"] == 3840 * 2160 * 12 // 2
+    assert lb["links_into_rank0"] == 1 and lb["packed12"]["bytes_into_rank0_per_frame"] == 1920 * 1080 * 12 // 2
     assert lb["rgba8"]["max_mrays_s"] == pytest.approx(3 * lb["packed12"]["max_mrays_s"], rel=1e-3)
-    assert cfg["also"]["workload"] == "terrain16_1080p" and cfg["also"]["value"] > 0
+    k4 = cfg["also"]
+    assert k4["workload"] == "terrain16_4k" and k4["value"] > 0 and k4["also_rgba8"]["value"] > 0 and k4["one_gpu_same_workload"]["value"] > 0
+    assert k4["link_bound"]["packed12"]["bytes_into_rank0_per_frame"] == 3840 * 2160 * 12 // 2
 
 
 def test_bench_line_fields(pkg, gpu):

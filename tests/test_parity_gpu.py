@@ -867,6 +867,32 @@ def test_config5_fractal_depth20(pkg, gpu, O):
         gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
 
 
+def test_deep_stack_limit_depth22_and_beyond(pkg, gpu, O):
+    """Round 4: the STACK variant's path codes have 23 bits, i.e. resolve 22 levels.  A depth-22 tree runs on the deep-stack
+    instantiation, a depth-23 tree is handed to the general kernel by SVO_OPT_TREE_DEPTH = 23 (and refused loudly by the deep-stack
+    kernel if the option claims 22) -- records equal the oracle's either way."""
+    gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+    try:
+        for depth in (22, 23):
+            words = pkg.scenes.fractal(seed=0, max_depth=depth, cam=(-0.99999, -0.99999, -0.99999), lod_c=300.0, min_depth=4, max_words=6_000_000)
+            assert pkg.scenes.max_depth(words) == depth
+            u = O.make_uniforms(pos=(-0.99990, -0.99985, -0.99980), look=(-1.0, -1.2, -0.9), width=192, height=108, flags=O.F_PAUSE_ADAPTIVE)
+            want = O.trace_frame(words, u, threads=8)
+            render = pkg.Render(gpu, (192, 108), words, capacity=words.size)
+            set_uniforms_from_oracle(render, u)
+            gpu.set_option(pkg.gpu.OPT_TREE_DEPTH, depth)
+            got = pkg.render.hits_to_numpy(render.render())
+            gpu.sync()
+            assert_hits_equal(got, want, f"fractal depth {depth}, SVO_OPT_TREE_DEPTH {depth}")
+            if depth == 23:
+                gpu.set_option(pkg.gpu.OPT_TREE_DEPTH, 22)  # a lie: the deep-stack kernel must notice
+                render.render()
+                with pytest.raises(pkg.SvoError):
+                    gpu.sync()
+    finally:
+        gpu.set_option(pkg.gpu.OPT_TREE_DEPTH, 16)
+
+
 def test_bench_workload_full_size(pkg, gpu, O):
     """The benchmark configuration at its full size (depth-16 terrain, ~107 M words, 1920x1080): the whole frame
     against the oracle, frame-to-frame idempotence under the adaptive schedule, and tile sharding == full frame."""
