@@ -28,6 +28,9 @@
 #ifndef SVO_TOP_IN_LDS   // 0: the top table is read from global memory (2 KiB less LDS per workgroup)
 #define SVO_TOP_IN_LDS 1
 #endif
+#ifndef SVO_CAM_SCALAR
+#define SVO_CAM_SCALAR 0
+#endif
 #ifndef SVO_WAVES_PER_SIMD_CNT   // of the counting instantiations (hit counters live)
 #define SVO_WAVES_PER_SIMD_CNT 6
 #endif
@@ -674,7 +677,11 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     // (Not with live hit counters: the copied leaf word would carry the counter bits it had when the wave started, and
     // every ray's compare-and-swap on that one word would fail once -- two million serialised atomics on one address.)
     constexpr bool CAM = !CNT;
+    // (kCamScalar: the camera's walk in eighteen scalar registers instead of the lanes of one vector register -- a build-time trial:
+    // the compiler parks the array in vector registers and spills, 52 bytes of scratch, so it stays off)
+    constexpr bool kCamScalar = SVO_CAM_SCALAR != 0 && NS <= 12;
     uint32_t camv = 0;
+    uint32_t cam_rows[NS] = {}, cam_leaf_off = 0, cam_leaf_w = 0, cam_sh = 0, cam_mu0 = 0, cam_mu1 = 0, cam_mu2 = 0;
     bool cam_ok = false;  // wave-uniform
     if (CAM && a.cam_shortcut && a.work.mode != 2) {
         const RayIn r0 = gen_ray(a.u, 0u, 0u);  // (the position does not depend on the pixel)
@@ -690,6 +697,16 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             v = lane == (uint32_t)NS + 1u ? leaf_w : v;
             v = lane == (uint32_t)NS + 2u ? sh : v;  // (D - the leaf's level)
             camv = v;
+            if (kCamScalar) {
+#pragma unroll
+                for (int l = 0; l < NS; l++) cam_rows[l] = (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+                cam_leaf_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf_off);
+                cam_leaf_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf_w);
+                cam_sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh);
+                cam_mu0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mu0);
+                cam_mu1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mu1);
+                cam_mu2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mu2);
+            }
             // worth it when the camera's leaf is deep (the copy at pick-up costs about two walk iterations)
             cam_ok = (uint32_t)D - (uint32_t)__builtin_amdgcn_readfirstlane(sh) >= (uint32_t)(SBASE + 2);
             stf = ST_IDLE;
@@ -848,31 +865,44 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                         Dr0 = __uint_as_float(pool[3 * 64 + e]);
                         Dr1 = __uint_as_float(pool[4 * 64 + e]);
                         Dr2 = __uint_as_float(pool[5 * 64 + e]);
-                        Y0 = 1.0f / Dr0;  // RN(1 / Dr): what div_by_recip wants (three IEEE divisions per pick-up instead of three
-                        Y1 = 1.0f / Dr1;  // more words per pooled ray: 8 words keep a workgroup at 22 KiB of LDS)
-                        Y2 = 1.0f / Dr2;
+                        // RN(1 / Dr), what div_by_recip wants, recomputed here instead of three more words per pooled ray (8 words keep a
+                        // workgroup at 22 KiB of LDS): v_rcp_f32 and one Newton step give the correctly rounded reciprocal for every
+                        // f32 of a clean ray's range (tools/rcptest_gpu.hip: all 2.85e9 of them, profiles/r04_rcptest.log)
+                        Y0 = recip_rn(Dr0);
+                        Y1 = recip_rn(Dr1);
+                        Y2 = recip_rn(Dr2);
                         S0 = copysign_bits(1.0f, Dr0);
                         S1 = copysign_bits(1.0f, Dr1);
                         S2 = copysign_bits(1.0f, Dr2);
                         dist = __uint_as_float(pool[6 * 64 + e]);
                         out = pool[7 * 64 + e];
-                        // entry path codes (the position may sit a rounding error outside the cube: clamp)
-                        mu0 = entry_magic<GE>(P0);
-                        mu1 = entry_magic<GE>(P1);
-                        mu2 = entry_magic<GE>(P2);
                         tcur = 0.0f;
                         stepsf = 0.0f;
                         nmf = 0.0f;
                         if (CAM && cam_ok && dist == 0.0f) {
-                            // a ray from the camera's own position: the walk the wave made at the start (see above)
-                            const uint32_t sh0 = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 2), L0 = (uint32_t)D - sh0;
-                            for (uint32_t l = 0; l < (uint32_t)NS && l + (uint32_t)SBASE <= L0; l++)
-                                lds[(uint32_t)TOFF + l * BLOCK + tid] = (uint32_t)__builtin_amdgcn_readlane((int)camv, (int)l);
-                            leaf_off = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS);
-                            leaf_w = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 1);
-                            sh = sh0;
+                            // a ray from the camera's own position: the walk the wave made at the start (see above), path codes included
+                            if (kCamScalar) {
+#pragma unroll
+                                for (int l = 0; l < NS; l++) lds[(uint32_t)TOFF + l * BLOCK + tid] = cam_rows[l];  // (rows below the leaf: never read)
+                                leaf_off = cam_leaf_off;
+                                leaf_w = cam_leaf_w;
+                                sh = cam_sh;
+                                mu0 = cam_mu0; mu1 = cam_mu1; mu2 = cam_mu2;
+                            } else {
+                                const uint32_t sh0 = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 2), L0 = (uint32_t)D - sh0;
+                                for (uint32_t l = 0; l < (uint32_t)NS && l + (uint32_t)SBASE <= L0; l++)
+                                    lds[(uint32_t)TOFF + l * BLOCK + tid] = (uint32_t)__builtin_amdgcn_readlane((int)camv, (int)l);
+                                leaf_off = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS);
+                                leaf_w = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 1);
+                                sh = sh0;
+                                mu0 = entry_magic<GE>(P0); mu1 = entry_magic<GE>(P1); mu2 = entry_magic<GE>(P2);
+                            }
                             stf = (kWalkStops && (leaf_w >> 4) != kVoxelOffset) ? ST_PENDING : ST_LEAF;  // at its leaf, no step taken
                         } else {
+                            // entry path codes (the position may sit a rounding error outside the cube: clamp)
+                            mu0 = entry_magic<GE>(P0);
+                            mu1 = entry_magic<GE>(P1);
+                            mu2 = entry_magic<GE>(P2);
                             stf = ST_DESC;
                             if (CNT) satm = 0u;
                             restart_at(1u);

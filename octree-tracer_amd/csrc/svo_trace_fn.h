@@ -282,6 +282,20 @@ __device__ __forceinline__ float div_by_recip(float a, float d, float y) {
     return __builtin_fmaf(r, y, q);
 }
 
+// RN(1 / d) for 2^-20 <= |d| <= 2^64: the hardware reciprocal (1 ulp) and one Newton step; equal to the IEEE division for every
+// such d (tools/rcptest_gpu.hip compares all of them; SVO_RECIP_IEEE=1 builds the division instead)
+#ifndef SVO_RECIP_IEEE
+#define SVO_RECIP_IEEE 0
+#endif
+__device__ __forceinline__ float recip_rn(float d) {
+#if SVO_RECIP_IEEE
+    return 1.0f / d;
+#else
+    const float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+#endif
+}
+
 // floor(x) and floor(-x) = -ceil(x) as integers in one instruction (|x| < 2^24 here, no saturation involved)
 __device__ __forceinline__ int32_t cvt_floor_i32(float x) {
     int32_t r;
