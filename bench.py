@@ -495,7 +495,7 @@ def main():
                     salu = tj.get("salu_wave_instructions_per_launch")
             # `bound` names the contractual ceiling (BASELINE.json: fraction of the HBM-read roofline on ALGORITHMIC bytes); what
             # the frame time actually follows is a balance of instruction issue and dependent-load latency: memory-side traffic is
-            # a fraction of the algorithmic bytes (L2 absorbs the shared ancestors), see roofline_valu and DESIGN.md 4.8 / 6
+            # a fraction of the algorithmic bytes (L2 absorbs the shared ancestors), see roofline_valu and DESIGN.md 4.7 / 6
             result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                   "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (not this run)",
@@ -503,7 +503,7 @@ def main():
                                   "measured_hbm_gbs": round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 2) if traffic else None,
                                   "measured_limiter": "not HBM bandwidth: the latency of the walk's dependent loads (half of a wave's time; L1 misses of a "
                                                       "69 % of wave-loads) against seven waves per SIMD, and the issue of the 4-cycle instruction group "
-                                                      "(DESIGN.md 4.9, 6; profiles/r04_*)",
+                                                      "(DESIGN.md 4.7, 6; profiles/r04_*)",
                                   "kernel": "trace_stack_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4),
                                   "algo_bytes_per_ray": round(bytes_per_ray, 3), "rays_per_launch": rays_per_launch}
             if valu:

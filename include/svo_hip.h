@@ -91,7 +91,7 @@ typedef struct svo_ctx svo_ctx;
 #define SVO_VARIANT_STACK 1   /* integer path codes + per-ray ancestor stack in LDS + LDS top table + refill (default) */
 /* (Round 3's two experiments over a device-built child-mask table -- one ray per lane, and two rays per lane software-pipelined --
  * measured slower than SVO_VARIANT_STACK on every scene and left the library in round 4; the source is kept under
- * tools/experiments/ with its logs in profiles/r03_*, DESIGN.md 4.8.  Values 2 and 3 are refused.) */
+ * tools/experiments/ with its logs in profiles/r03_*, DESIGN.md Appendix A.  Values 2 and 3 are refused.) */
 
 typedef enum svo_option {
     SVO_OPT_VARIANT = 0,

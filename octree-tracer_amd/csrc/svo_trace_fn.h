@@ -326,7 +326,7 @@ __device__ __forceinline__ float copysign_bits(float mag, float sgn) {
 // forms above are proven for.  pos is the entry point (|pos| <= 2 always holds for rays that enter).
 __device__ __forceinline__ bool clean_component(float p, float d) {
     float ap = fabsf(p), ad = fabsf(d);
-    bool p_ok = ap <= 2.0f;  // any magnitude below: scaling by 2^23 is exact, and A = (C - P) + H is 0 or >= 2^-26
+    bool p_ok = ap <= 2.0f;  // any magnitude below: scaling by 2^22 is exact, and A = (C - P) + H is 0 or >= 2^-27
     bool d_ok = (ad >= 9.094947017729282e-13f) && (ad <= 1099511627776.0f);     // 2^-40 .. 2^40
     return p_ok && d_ok;  // NaN fails both
 }

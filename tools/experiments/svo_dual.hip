@@ -1,4 +1,4 @@
-// svo_dual.hip -- round 3's experiment: the STACK traversal with TWO rays per lane, software-pipelined, over a
+// svo_dual.hip -- round 3's experiment (builds against commit 35128d4, the head of round 3): the STACK traversal with TWO rays per lane, software-pipelined, over a
 // child-mask table, for static trees.  It does what it was built for -- waves wait at s_waitcnt half as long, a DDA step costs 1.05
 // loads instead of 1.8 -- and is 2.5 x SLOWER than trace_stack_kernel on the benchmark frame: 1.75 x the instructions per frame, and a
 // ray advances once per loop iteration of two turns, which stretches the serial chain of the 101-step rays past the whole frame.  It
