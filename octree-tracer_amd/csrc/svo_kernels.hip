@@ -21,7 +21,7 @@
 #include "svo_device.h"
 #include "svo_trace_fn.h"
 
-// Build-time switches kept for same-box A/B builds (-DSVO_...=n); the defaults are what measured fastest (DESIGN.md 4.9).
+// Build-time switches kept for same-box A/B builds (-DSVO_...=n); the defaults are what measured fastest (DESIGN.md 4.7, Appendix A).
 #ifndef SVO_WALK_STOP
 #define SVO_WALK_STOP 1
 #endif
@@ -1611,7 +1611,7 @@ __global__ __launch_bounds__(256) void strip_classes_kernel(const uint8_t *skip,
 
 // Strips whose rays all miss the cube (sky): decided per 64-pixel block from the four corner rays, before the trace, so
 // that such strips are never claimed, generated or refilled from -- on frames that are mostly sky that is most of the
-// per-strip work (DESIGN.md 4.6).  The rays of a block are pos + s * (point(pixel) - pos), s > 0, where point() is the
+// per-strip work (DESIGN.md 4.5).  The rays of a block are pos + s * (point(pixel) - pos), s > 0, where point() is the
 // projective image of the pixel under camera_inverse: the block's points lie in the planar convex quadrilateral Q of its
 // four corner pixels (same sign of w at the corners), so every ray lies in the cone over Q with apex pos.  If one side
 // plane of that cone (through pos and an edge of Q, normal n pointing into the cone) has the whole cube strictly on its
