@@ -28,6 +28,9 @@
 #ifndef SVO_TOP_IN_LDS   // 0: the top table is read from global memory (2 KiB less LDS per workgroup)
 #define SVO_TOP_IN_LDS 1
 #endif
+#ifndef SVO_WALK_TRIPS   // 1: the walk's depth limit is a count of its iterations (wave-uniform) instead of a test of every lane's level
+#define SVO_WALK_TRIPS 1
+#endif
 #ifndef SVO_CAM_SCALAR
 #define SVO_CAM_SCALAR 0
 #endif
@@ -294,7 +297,11 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     static_assert(SMAX <= D - 1, "stack deeper than the path codes");
     constexpr int TBL = 1 << (3 * K);
     constexpr bool kTopInLds = SVO_TOP_IN_LDS != 0;
-    constexpr int TOFF = kTopInLds ? TBL : 0;  // LDS words in front of the ancestor stacks
+    constexpr int TOFF = kTopInLds ? TBL : 0;  // LDS words in front of the ray pools
+    // The ancestor stacks come LAST in the workgroup's LDS: the walk below does not check the level it has reached (two instructions
+    // per word), so in a tree deeper than the caller declared a lane pushes rows that do not exist -- beyond the allocation, where
+    // the hardware drops the write (and reads return 0: tools/experiments/lds_oob_probe.hip) instead of into another ray's data.
+    constexpr int SOFF = TOFF + (BLOCK / 64) * (kPoolWords * 64) + (CNT ? (BLOCK / 64) * kCountQueue + kSatTags + TBL / 8 : 0);
     static_assert(D == 23, "2^D + code must be an f32 with unit spacing");
     constexpr float kScale = (float)(1 << (D - 1));  // 2^22: grid units per unit of the cube
     constexpr float kInvScale = 1.0f / kScale;
@@ -317,8 +324,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     }
     extern __shared__ uint32_t lds[];
     const uint32_t *tbl = kTopInLds ? lds : a.top_table;  // TBL entries
-    uint32_t *stk = lds + TOFF;                   // [NS][BLOCK]
-    uint32_t *pool_all = stk + NS * BLOCK;  // [BLOCK / 64][kPoolWords][64]
+    uint32_t *pool_all = lds + TOFF;  // [BLOCK / 64][kPoolWords][64]; behind them the counting queues and tables (CNT), then the stacks [NS][BLOCK]
     // CNT: level-1 / level-2 cell -> child group (kTopAuxEntries words behind the top table): read from global memory, where the
     // 288 bytes stay in the L1 -- in LDS they cost the sixth workgroup per CU (the allocation granule)
     const uint32_t *aux = a.top_table + TBL;
@@ -511,18 +517,23 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     // sh: at a leaf, the bit of the path codes that selects the child at the leaf's level, D - L (the leaf's cell is 2^sh grid
     // units wide); before a walk, one more than the bit of the first level to read.  nidx: the child group that level lives in.
     uint32_t sh = 1, nidx = 0;
-    uint32_t sp = ((uint32_t)TOFF + threadIdx.x) * 4u;  // LDS slot (byte offset) one row BELOW the walk's next push
+    uint32_t sp = ((uint32_t)SOFF + threadIdx.x) * 4u;  // LDS slot (byte offset) one row BELOW the walk's next push
     uint32_t leaf_off = 0, leaf_w = 0;  // current leaf: byte offset of its word, and the word
     auto sabs = [](float x) -> float { return SHD ? __builtin_fabsf(x) : x; };  // (only the SHD instantiation has negative states)
     constexpr bool kWalkStops = SVO_WALK_STOP != 0 && !CNT;
+    constexpr bool kWalkTrips = SVO_WALK_TRIPS != 0;
     uint32_t satm = 0;                // CNT: bit l = the word of level l on the lane's current path is known to be saturated (step 3a)
 
     // (re)start a descent: from the LDS top table when the restart level r is at most K+1 (the table also
     // knows leaves that cover a whole level-K cell), else from the lane's ancestor stack.  One LDS read.
-    auto lds_at = [&](uint32_t byte_offset) -> uint32_t & { return *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + byte_offset); };
+    // LDS by plain byte address: through `lds` -- a symbol whose address the linker fills in -- every access costs a v_add of that
+    // address, which is 0 (the kernel has no static LDS, so the dynamic array starts at the bottom: checked, at compile time in effect)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    auto lds_at = [&](uint32_t byte_offset) -> lds_u32 & { return *(lds_u32 *)(uintptr_t)byte_offset; };
+    if (__builtin_amdgcn_groupstaticsize() != 0u) __builtin_trap();
     auto restart_at = [&](uint32_t r) {
         const bool top = r <= (uint32_t)(K + 1);
-        const uint32_t addr = ((uint32_t)TOFF + tid) * 4u + (r - SBASE) * (uint32_t)(BLOCK * 4);  // stack[r - SBASE][lane], in bytes
+        const uint32_t addr = ((uint32_t)SOFF + tid) * 4u + (r - SBASE) * (uint32_t)(BLOCK * 4);  // stack[r - SBASE][lane], in bytes
         if (__ballot(top)) {  // wave-uniform: most rounds no lane crosses a level-(K+1) boundary
             const uint32_t cell = (__builtin_amdgcn_ubfe(mu0, D - K, K) << (2 * K)) | (__builtin_amdgcn_ubfe(mu1, D - K, K) << K) |
                                   __builtin_amdgcn_ubfe(mu2, D - K, K);
@@ -530,7 +541,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             sh = (uint32_t)(D + 1) - (top ? (e >> 27) : r);
             nidx = e & 0x07FFFFFFu;
             // a walk from the table starts at level K+1 or above: its first push (if any) is the group of level K+2, row 0
-            sp = top ? ((uint32_t)TOFF + tid) * 4u - (uint32_t)(BLOCK * 4) : addr;
+            sp = top ? ((uint32_t)SOFF + tid) * 4u - (uint32_t)(BLOCK * 4) : addr;
         } else {  // a stack entry is the child group itself (< 2^27): nothing to unpack
             sh = (uint32_t)(D + 1) - r;
             nidx = lds_at(addr);
@@ -650,16 +661,25 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                 if (CNT) satm |= ((w & 15u) == 15u ? 1u : 0u) << ((uint32_t)D - sh);  // (a counter never goes down within a frame)
                 c = child_below();  // (sh now points one level below the word in flight)
                 // sign bit: a leaf (word >= VOXEL_OFFSET << 4), or level SMAX reached (deeper trees are refused)
-                key = w | (sh - (uint32_t)(D - SMAX));
+                key = kWalkTrips ? w : (w | (sh - (uint32_t)(D - SMAX)));
             };
             read_word();
-            while ((int32_t)key >= 0) {
+            // kWalkTrips: a walk reads at most NS words below its first one in a tree of the declared depth -- the last of them, at level
+            // SMAX, a leaf.  In a deeper tree the count (one scalar subtraction per iteration instead of two vector instructions per lane)
+            // ends the walk; lanes that started low have gone past level SMAX by then: their pushes fell off the end of the LDS
+            // allocation (see SOFF).  A word found below level SMAX is handed on as an interior word, which is what the walk of rounds
+            // 1-3 stopped at: the ray ends there with the "too deep" record and svo_sync reports the frame.
+            uint32_t trips = (uint32_t)NS;
+            while ((int32_t)key >= 0 && (!kWalkTrips || trips != 0u)) {
+                if (kWalkTrips) trips -= 1u;
                 nidx = w >> 4;
                 sp += (uint32_t)(BLOCK * 4);
+                if (kWalkTrips) asm("" : "+v"(sp));  // (keeps the compiler from turning sp into base + a scalar: one more v_add per iteration)
                 lds_at(sp) = nidx;
                 read_word();
             }
             sh += 1u;  // back to the leaf's own bit
+            if (kWalkTrips) w = (int32_t)sh >= D - SMAX ? w : 0u;  // (signed: 2^D + code has no bits below level D, sh may have passed 0)
             leaf_off = off;
             leaf_w = w;
             // ST_DESC -> ST_LEAF; or straight to ST_PENDING when the ray ends in this leaf (anything but an empty leaf: a solid one, or
@@ -692,7 +712,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             stf = ST_DESC;
             restart_at(1u);
             descend();
-            uint32_t v = lane < (uint32_t)NS ? lds[(uint32_t)TOFF + lane * BLOCK + tid] : 0u;  // row `lane` of this lane's own column
+            uint32_t v = lane < (uint32_t)NS ? lds[(uint32_t)SOFF + lane * BLOCK + tid] : 0u;  // row `lane` of this lane's own column
             v = lane == (uint32_t)NS ? leaf_off : v;
             v = lane == (uint32_t)NS + 1u ? leaf_w : v;
             v = lane == (uint32_t)NS + 2u ? sh : v;  // (D - the leaf's level)
@@ -883,7 +903,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                             // a ray from the camera's own position: the walk the wave made at the start (see above), path codes included
                             if (kCamScalar) {
 #pragma unroll
-                                for (int l = 0; l < NS; l++) lds[(uint32_t)TOFF + l * BLOCK + tid] = cam_rows[l];  // (rows below the leaf: never read)
+                                for (int l = 0; l < NS; l++) lds[(uint32_t)SOFF + l * BLOCK + tid] = cam_rows[l];  // (rows below the leaf: never read)
                                 leaf_off = cam_leaf_off;
                                 leaf_w = cam_leaf_w;
                                 sh = cam_sh;
@@ -891,7 +911,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                             } else {
                                 const uint32_t sh0 = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 2), L0 = (uint32_t)D - sh0;
                                 for (uint32_t l = 0; l < (uint32_t)NS && l + (uint32_t)SBASE <= L0; l++)
-                                    lds[(uint32_t)TOFF + l * BLOCK + tid] = (uint32_t)__builtin_amdgcn_readlane((int)camv, (int)l);
+                                    lds[(uint32_t)SOFF + l * BLOCK + tid] = (uint32_t)__builtin_amdgcn_readlane((int)camv, (int)l);
                                 leaf_off = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS);
                                 leaf_w = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 1);
                                 sh = sh0;
@@ -944,7 +964,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             const bool at_leaf = sabs(stf) == ST_LEAF;
             const uint64_t c_c0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
             if (__ballot(at_leaf) != 0ull) {
-                const uint32_t L = (uint32_t)D - sh;
+                const uint32_t L = min((uint32_t)D - sh, (uint32_t)SMAX);  // (a word below level SMAX ends the ray: the tree is deeper than declared)
                 uint32_t todo = at_leaf ? (~satm & ((1u << L) - 2u)) : 0u;  // levels 1 .. L-1 not known to be saturated
                 constexpr uint32_t kTopLv = (2u << K) - 2u;  // levels 1 .. K
                 auto cell_k = [&]() -> uint32_t {
@@ -967,7 +987,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                     const uint32_t kk = l - 1u, shc = (uint32_t)D - kk;
                     uint32_t g = 0u;
                     if (l >= (uint32_t)SBASE) {
-                        g = lds[(uint32_t)TOFF + (l - (uint32_t)SBASE) * BLOCK + tid];
+                        g = lds[(uint32_t)SOFF + (l - (uint32_t)SBASE) * BLOCK + tid];
                     } else if (l >= 2u) {
                         const uint32_t cell = (__builtin_amdgcn_ubfe(mu0, shc, kk) << (2u * kk)) | (__builtin_amdgcn_ubfe(mu1, shc, kk) << kk) | __builtin_amdgcn_ubfe(mu2, shc, kk);
                         g = kk == (uint32_t)K ? (tbl[cell] & 0x07FFFFFFu) : aux[(kk == 1u ? 0u : 8u) + cell];
@@ -1552,8 +1572,9 @@ static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipS
         // The occupancy query does not round LDS up to the allocation granule; measured on MI355X, 336 bytes on top of
         // 26 KiB per workgroup already cost the sixth workgroup per CU.  Workgroups that are not resident at launch
         // start when the first ones end and bring their reserved (longest) strips with them, so overestimating is
-        // far worse than underestimating: assume 1 KiB granules of the 160 KiB.
-        const int by_lds = (int)((160u * 1024u) / ((lds_bytes + 1023u) & ~(size_t)1023u));
+        // far worse than underestimating.  The granule is 1280 bytes (320 dwords): 512 bytes on top of this kernel's 22 KiB keep the
+        // seventh workgroup per CU, 528 lose it (profiles/r04_lds_granule_ab.log).
+        const int by_lds = (int)((160u * 1024u) / (((lds_bytes + 1279u) / 1280u) * 1280u));
         if (by_lds >= 1 && by_lds < blocks_per_cu) blocks_per_cu = by_lds;
     }
     uint32_t blocks = (uint32_t)li.num_cus * (uint32_t)blocks_per_cu;

@@ -893,6 +893,33 @@ def test_deep_stack_limit_depth22_and_beyond(pkg, gpu, O):
         gpu.set_option(pkg.gpu.OPT_TREE_DEPTH, 16)
 
 
+def test_tree_deeper_than_declared_is_refused(pkg, gpu, O):
+    """Round 4: the STACK walk counts its iterations instead of checking every lane's level, and the ancestor stacks lie at the end of
+    the workgroup's LDS so that a push below the last level falls off the allocation.  A tree deeper than SVO_OPT_TREE_DEPTH says --
+    18 and 23 levels under a declared 16, static and with live hit counters -- must still be refused by svo_sync, must not fault,
+    and the frames after it (same context, an honest tree) must be right."""
+    gpu.set_option(pkg.gpu.OPT_VARIANT, 1)
+    gpu.set_option(pkg.gpu.OPT_TREE_DEPTH, 16)
+    honest = pkg.scenes.fractal(seed=2, max_depth=12, cam=(-0.99, -0.99, -0.99), lod_c=200.0, min_depth=3, max_words=2_000_000)
+    u = O.make_uniforms(pos=(-0.99990, -0.99985, -0.99980), look=(-1.0, -1.2, -0.9), width=192, height=108, flags=O.F_PAUSE_ADAPTIVE)
+    for depth in (18, 23):
+        words = pkg.scenes.fractal(seed=0, max_depth=depth, cam=(-0.99999, -0.99999, -0.99999), lod_c=300.0, min_depth=4, max_words=6_000_000)
+        assert pkg.scenes.max_depth(words) == depth
+        for flags in (O.F_PAUSE_ADAPTIVE, 0):
+            render = pkg.Render(gpu, (192, 108), words, capacity=words.size)
+            uu = O.make_uniforms(pos=(-0.99990, -0.99985, -0.99980), look=(-1.0, -1.2, -0.9), width=192, height=108, flags=flags)
+            set_uniforms_from_oracle(render, uu)
+            render.render()
+            with pytest.raises(pkg.SvoError):
+                gpu.sync()
+            del render
+        render = pkg.Render(gpu, (192, 108), honest, capacity=honest.size)
+        set_uniforms_from_oracle(render, u)
+        got = pkg.render.hits_to_numpy(render.render())
+        gpu.sync()
+        assert_hits_equal(got, O.trace_frame(honest, u, threads=8), f"honest tree after the refused depth-{depth} one")
+
+
 def test_bench_workload_full_size(pkg, gpu, O):
     """The benchmark configuration at its full size (depth-16 terrain, ~107 M words, 1920x1080): the whole frame
     against the oracle, frame-to-frame idempotence under the adaptive schedule, and tile sharding == full frame."""

@@ -458,6 +458,30 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned *out, unsigned long 
             OPS(BLOCK8x8(X));
 #undef X
             asm volatile("s_mov_b64 exec, %0" : : "s"(sv));
+        } else if (KIND == 116) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\t");
+        } else if (KIND == 117) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\t");
+        } else if (KIND == 118) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_add_u32 %2, %2, %18\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_add_u32 %6, %6, %18\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_add_u32 %2, %2, %18\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_add_u32 %6, %6, %18\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_add_u32 %2, %2, %18\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_add_u32 %6, %6, %18\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_add_u32 %2, %2, %18\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_add_u32 %6, %6, %18\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_add_u32 %2, %2, %18\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_add_u32 %6, %6, %18\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_add_u32 %2, %2, %18\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_add_u32 %6, %6, %18\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_add_u32 %2, %2, %18\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_add_u32 %6, %6, %18\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_add_u32 %2, %2, %18\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_add_u32 %6, %6, %18\n\tv_add_f32 %7, %7, %17\n\t");
+        } else if (KIND == 119) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\t");
+        } else if (KIND == 120) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_add_u32 %0, %0, %18\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_add_u32 %0, %0, %18\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_add_u32 %0, %0, %18\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_add_u32 %0, %0, %18\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\t");
+        } else if (KIND == 121) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\t");
+        } else if (KIND == 122) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\t");
+        } else if (KIND == 123) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_u32 %7, %7, %18\n\t");
+        } else if (KIND == 124) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_bfe_u32 %1, %1, %18, 7\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_bfe_u32 %3, %3, %18, 7\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_bfe_u32 %5, %5, %18, 7\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_bfe_u32 %7, %7, %18, 7\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\t");
+        } else if (KIND == 125) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_add_u32 %0, %0, %18\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_f32 %1, %1, %17\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_f32 %5, %5, %17\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_add_u32 %0, %0, %18\n\tv_add_f32 %1, %1, %17\n\tv_add_f32 %2, %2, %17\n\tv_add_f32 %3, %3, %17\n\tv_add_f32 %4, %4, %17\n\tv_add_f32 %5, %5, %17\n\tv_add_f32 %6, %6, %17\n\tv_add_f32 %7, %7, %17\n\t");
+        } else if (KIND == 126) {
+            OPS("v_add_u32 %0, %0, %18\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_add_u32 %0, %0, %18\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_add_u32 %0, %0, %18\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_add_u32 %0, %0, %18\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_add_u32 %0, %0, %18\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_add_u32 %0, %0, %18\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_add_u32 %0, %0, %18\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\tv_add_u32 %0, %0, %18\n\tv_add_u32 %1, %1, %18\n\tv_add_u32 %2, %2, %18\n\tv_add_u32 %3, %3, %18\n\tv_add_u32 %4, %4, %18\n\tv_add_u32 %5, %5, %18\n\tv_add_u32 %6, %6, %18\n\tv_add_u32 %7, %7, %18\n\t");
+        } else if (KIND == 127) {
+            OPS("v_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\tv_bfe_u32 %0, %0, %18, 7\n\tv_add_u32 %1, %1, %18\n\tv_bfe_u32 %2, %2, %18, 7\n\tv_add_f32 %3, %3, %17\n\tv_bfe_u32 %4, %4, %18, 7\n\tv_add_u32 %5, %5, %18\n\tv_bfe_u32 %6, %6, %18, 7\n\tv_add_f32 %7, %7, %17\n\t");
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), q1 = __builtin_amdgcn_s_memrealtime();
@@ -479,8 +503,9 @@ static const char *kNames[] = {
     "v_xad_u32", "v_add3_u32", "v_and_b32_sdwa", "v_mov_b32_dpp",
     "v_cndmask_b32_e64 (vcc as mask)", "v_cndmask_e32 vcc : v_add_u32 1:1", "v_cndmask_e32 vcc : v_add_u32 1:3", "v_cndmask sgpr : v_add_u32 1:1", "v_bfe_u32 : v_add_u32 1:1", "v_bfe_u32 : v_add_u32 1:3", "v_lshlrev_b32 (imm)", "v_lshrrev_b32 (reg)", "v_ashrrev_i32 (imm)", "v_and_b32", "v_or_b32", "v_sub_u32", "v_max_f32", "v_max_u32", "v_med3_f32", "v_cmp_lt_u32 -> vcc", "v_cmp_class_f32 -> vcc", "v_mul_lo_u32", "v_and_b32 + literal", "v_add_f32 (sgpr src)", "v_mul_f32 (inline const)", "v_xor_b32 (sgpr src)", "v_sub_f32_e64 abs/neg", "v_mul_f32 : v_bfe : v_cmp mix", "v_cvt_f32_ubyte0", "v_mbcnt_lo_u32_b32", "v_subrev_u32", "v_lshlrev_b32 (sgpr amount)", "v_mul_f32 (2 vgpr, distinct)", 
     "indep: bfe,addu (S F)", "indep: bfe,addu,xor,addu (S F F F)", "indep: bfe,bfe,addu,addu (S S F F)", "indep: bfe,addf (S Ff)", "indep: bfe,mulf,addf,fma (S Ff Ff Ff)", "indep: mulf,bfe,addf,cmp", "indep: cmp,addf (S Ff)", "indep: cmp,addu (S F)", "indep: cvt,addf (S Ff)", "indep: minf,addf (S Ff)", "indep: lshl_or,addu,addu (S F F)", "indep: addu,addf (F Ff)", "indep: 7F 1S (addf x7, bfe)", "indep: 4F 4S blocks", "indep: 16F 16S blocks", 
-    "v_floor_f32", "v_ldexp_f32", "v_fract_f32", "v_trunc_f32", "v_rndne_f32", "v_mul_f32_e64 clamp", "v_fma_f32 clamp", "v_frexp_exp_i32_f32", "v_cvt_u32_f32", "v_mul_f32 literal", "indep: floor,addf,mulf,fma (S Ff Ff Ff)", "indep: bfe,addf,addf (S Ff Ff)", "indep: bfe,fma clamp (S Fc)", "indep: bfe,bfe,addf (S S Ff)", "indep: bfe,addu,addf (S I Ff)", "indep: addu,addf,addf (I Ff Ff)", "indep: xor,bfe,addf,addf (I S Ff Ff)", "indep: mov,bfe (I S)", "indep: lshrrev,bfe (I S)", "indep: and,bfe (I S)", "v_cmpx_ge_u32 (always true)"};
-constexpr int kKinds = 116;
+    "v_floor_f32", "v_ldexp_f32", "v_fract_f32", "v_trunc_f32", "v_rndne_f32", "v_mul_f32_e64 clamp", "v_fma_f32 clamp", "v_frexp_exp_i32_f32", "v_cvt_u32_f32", "v_mul_f32 literal", "indep: floor,addf,mulf,fma (S Ff Ff Ff)", "indep: bfe,addf,addf (S Ff Ff)", "indep: bfe,fma clamp (S Fc)", "indep: bfe,bfe,addf (S S Ff)", "indep: bfe,addu,addf (S I Ff)", "indep: addu,addf,addf (I Ff Ff)", "indep: xor,bfe,addf,addf (I S Ff Ff)", "indep: mov,bfe (I S)", "indep: lshrrev,bfe (I S)", "indep: and,bfe (I S)", "v_cmpx_ge_u32 (always true)",
+    "indep: 4S 4I blocks", "indep: 2S 2I blocks", "indep: S F I F", "indep: S I F F", "indep: SFSFSFSF IIII FFFF", "indep: S I I I", "indep: S I I I F F F F", "walk-like: SSIIII SSSSS II SS I (9S 7I)", "walk-like grouped: 9S then 7I", "walk-like + 16 F beside: 9S 7I 16F", "v_add_u32 x8 (check)", "indep: S I S F"};
+constexpr int kKinds = 128;
 
 template <int K>
 void launch(int blocks, unsigned *out, unsigned long long *clk, int iters) {
