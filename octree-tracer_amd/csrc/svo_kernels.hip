@@ -31,6 +31,9 @@
 #ifndef SVO_WALK_TRIPS   // 1: the walk's depth limit is a count of its iterations (wave-uniform) instead of a test of every lane's level
 #define SVO_WALK_TRIPS 1
 #endif
+#ifndef SVO_WALK_ASM   // 1: the walk's loop hand-written (default instantiation): what follows a word's arrival is a compare, one scalar
+#define SVO_WALK_ASM 1  // instruction on the execute mask and the branch
+#endif
 #ifndef SVO_CAM_SCALAR
 #define SVO_CAM_SCALAR 0
 #endif
@@ -333,6 +336,11 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     const uint32_t lane = tid & 63u;
     uint32_t *pool = pool_all + (tid >> 6) * (kPoolWords * 64);
     const rsrc_t rs = make_rsrc(a.nodes, a.n_words);
+    // (the same descriptor as four scalar words, for the hand-written loop of the walk: raw buffer, stride 0, size in bytes)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 rs_asm = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)a.nodes),
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)a.nodes >> 32)) & 0xFFFFu,
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.n_words << 2)), 0x00020000u};
     uint32_t c_refill = 0, c_desc = 0, c_step = 0, c_gen = 0, dbg_desc_iters = 0, dbg_desc_lanes = 0, dbg_desc_rounds = 0, dbg_desc_start = 0;
     // CNT: the visits of a round are not added to the counters on the spot -- a compare-and-swap is executed at the memory
     // side (the L2s of the 8 XCDs are not coherent with each other), its answer takes 0.4 - 1.3 us under this kernel's load,
@@ -516,12 +524,18 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     uint32_t mu0 = __float_as_uint(kMagic), mu1 = mu0, mu2 = mu0;  // path codes, as the bits of kMagic + code
     // sh: at a leaf, the bit of the path codes that selects the child at the leaf's level, D - L (the leaf's cell is 2^sh grid
     // units wide); before a walk, one more than the bit of the first level to read.  nidx: the child group that level lives in.
-    uint32_t sh = 1, nidx = 0;
+    // (sh lives in its register as the bits of the float 2^23 + sh, like the path codes: the walk's decrement is then an f32 add -- which
+    // issues beside the bit-field extracts for nothing, tools/issue_rate.hip -- and the instructions that take sh as a bit position or a
+    // shift amount read the low five bits only.  sh_of() where the number itself is wanted.)
+    uint32_t sh = __float_as_uint(kMagic + 1.0f), nidx = 0;
+    auto sh_of = [](uint32_t shbits) -> uint32_t { return shbits & 31u; };
+    constexpr uint32_t kShMagic = 0x4B000000u;  // bits of 2^23
     uint32_t sp = ((uint32_t)SOFF + threadIdx.x) * 4u;  // LDS slot (byte offset) one row BELOW the walk's next push
     uint32_t leaf_off = 0, leaf_w = 0;  // current leaf: byte offset of its word, and the word
     auto sabs = [](float x) -> float { return SHD ? __builtin_fabsf(x) : x; };  // (only the SHD instantiation has negative states)
     constexpr bool kWalkStops = SVO_WALK_STOP != 0 && !CNT;
     constexpr bool kWalkTrips = SVO_WALK_TRIPS != 0;
+    constexpr bool kWalkAsm = SVO_WALK_ASM != 0 && kWalkTrips && !CNT && !DBG;
     uint32_t satm = 0;                // CNT: bit l = the word of level l on the lane's current path is known to be saturated (step 3a)
 
     // (re)start a descent: from the LDS top table when the restart level r is at most K+1 (the table also
@@ -531,23 +545,25 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     auto lds_at = [&](uint32_t byte_offset) -> lds_u32 & { return *(lds_u32 *)(uintptr_t)byte_offset; };
     if (__builtin_amdgcn_groupstaticsize() != 0u) __builtin_trap();
-    auto restart_at = [&](uint32_t r) {
-        const bool top = r <= (uint32_t)(K + 1);
-        const uint32_t addr = ((uint32_t)SOFF + tid) * 4u + (r - SBASE) * (uint32_t)(BLOCK * 4);  // stack[r - SBASE][lane], in bytes
+    // rb = r + (31 - D): the step has r as a count of leading zeros, and every use of it here takes a constant anyway
+    constexpr uint32_t kRb = (uint32_t)(31 - D);
+    auto restart_at_rb = [&](uint32_t rb) {
+        const bool top = rb <= (uint32_t)(K + 1) + kRb;
+        sp = ((uint32_t)SOFF + tid) * 4u - (kRb + (uint32_t)SBASE) * (uint32_t)(BLOCK * 4) + rb * (uint32_t)(BLOCK * 4);  // stack[r - SBASE][lane], in bytes
         if (__ballot(top)) {  // wave-uniform: most rounds no lane crosses a level-(K+1) boundary
             const uint32_t cell = (__builtin_amdgcn_ubfe(mu0, D - K, K) << (2 * K)) | (__builtin_amdgcn_ubfe(mu1, D - K, K) << K) |
                                   __builtin_amdgcn_ubfe(mu2, D - K, K);
-            const uint32_t e = kTopInLds ? lds_at(top ? cell * 4u : addr) : (top ? a.top_table[cell] : lds_at(addr));
-            sh = (uint32_t)(D + 1) - (top ? (e >> 27) : r);
+            const uint32_t e = kTopInLds ? lds_at(top ? cell * 4u : sp) : (top ? a.top_table[cell] : lds_at(sp));
+            sh = (kShMagic + (uint32_t)(D + 1)) - (top ? (e >> 27) : rb - kRb);
             nidx = e & 0x07FFFFFFu;
             // a walk from the table starts at level K+1 or above: its first push (if any) is the group of level K+2, row 0
-            sp = top ? ((uint32_t)SOFF + tid) * 4u - (uint32_t)(BLOCK * 4) : addr;
-        } else {  // a stack entry is the child group itself (< 2^27): nothing to unpack
-            sh = (uint32_t)(D + 1) - r;
-            nidx = lds_at(addr);
-            sp = addr;  // (the walk's first push goes to the row of level r + 1)
+            sp = top ? ((uint32_t)SOFF + tid) * 4u - (uint32_t)(BLOCK * 4) : sp;
+        } else {  // a stack entry is the child group itself (< 2^27): nothing to unpack; the walk's first push goes to the row of level r + 1
+            sh = (kShMagic + (uint32_t)(D + 1) + kRb) - rb;
+            nidx = lds_at(sp);
         }
     };
+    auto restart_at = [&](uint32_t r) { restart_at_rb(r + kRb); };
 
     // write the record of a finished ray (deferred to the next refill so that it runs for many lanes at once)
     auto flush_record = [&](bool may_continue) {
@@ -556,10 +572,10 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
         const uint32_t steps = (uint32_t)stepsf;
         // a ray that ends without stopping in its leaf left the cube -- its count is at most 100 -- or ran into the step limit,
         // which is the one way to count 101 (shader.wgsl:237-244)
-        const bool too_deep = leaf_w < (kVoxelOffset << 4), solid = (leaf_w >> 4) != kVoxelOffset, inb = steps == 101u;
+        const bool too_deep = leaf_w < (kVoxelOffset << 4) || (kWalkTrips && __uint_as_float(sh) < kMagic + (float)(D - SMAX)), solid = (leaf_w >> 4) != kVoxelOffset, inb = steps == 101u;
         const bool stop_here = too_deep || solid;
         if (too_deep) atomicOr(a.status, 1u);  // reported by svo_sync
-        const uint32_t L = (uint32_t)D - sh, nm = (uint32_t)__builtin_fmaf(nmf, 1.0f / kNudge, 0.5f);  // (nmf is 0 .. 7 times k, up to rounding)
+        const uint32_t L = (uint32_t)D - sh_of(sh), nm = (uint32_t)__builtin_fmaf(nmf, 1.0f / kNudge, 0.5f);  // (nmf is 0 .. 7 times k, up to rounding)
         uint32_t c0n = (Dr0 > 0.0f) ? 2u : 1u, c1n = (Dr1 > 0.0f) ? 2u : 1u, c2n = (Dr2 > 0.0f) ? 2u : 1u;
         uint32_t ncode = ((nm & 1u) ? c0n : 0u) | ((nm & 2u) ? (c1n << 2) : 0u) | ((nm & 4u) ? (c2n << 4) : 0u);
         if (steps == 0u) ncode = out >> 26;               // no step taken: the entry normal
@@ -631,7 +647,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             // keeping the decrement inside saves a copy of the counter)
             auto child_below = [&]() -> uint32_t {
                 uint32_t c, tmp;
-                asm("v_add_u32 %2, -1, %2\n\t"
+                asm("v_add_f32 %2, -1.0, %2\n\t"
                     "v_bfe_u32 %0, %3, %2, 1\n\t"
                     "v_bfe_u32 %1, %4, %2, 1\n\t"
                     "v_lshl_or_b32 %0, %0, 1, %1\n\t"
@@ -658,10 +674,10 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                 tally();
                 off = (nidx + c) << 2;
                 w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
-                if (CNT) satm |= ((w & 15u) == 15u ? 1u : 0u) << ((uint32_t)D - sh);  // (a counter never goes down within a frame)
+                if (CNT) satm |= ((w & 15u) == 15u ? 1u : 0u) << (((uint32_t)D - sh_of(sh)) & 31u);  // (a counter never goes down within a frame)
                 c = child_below();  // (sh now points one level below the word in flight)
                 // sign bit: a leaf (word >= VOXEL_OFFSET << 4), or level SMAX reached (deeper trees are refused)
-                key = kWalkTrips ? w : (w | (sh - (uint32_t)(D - SMAX)));
+                key = kWalkTrips ? w : (w | (sh_of(sh) - (uint32_t)(D - SMAX)));
             };
             read_word();
             // kWalkTrips: a walk reads at most NS words below its first one in a tree of the declared depth -- the last of them, at level
@@ -670,21 +686,71 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             // allocation (see SOFF).  A word found below level SMAX is handed on as an interior word, which is what the walk of rounds
             // 1-3 stopped at: the ray ends there with the "too deep" record and svo_sync reports the frame.
             uint32_t trips = (uint32_t)NS;
+            if (kWalkAsm) {
+                // The same loop as below, instruction for instruction, but for its control: the compiler keeps the lanes that have
+                // left in a second mask and folds the count's flag into it -- four scalar instructions between a word's arrival
+                // and the next load; every instruction there costs the walk its latency (profiles/r04_walk_critical_path_ab.log).
+                if ((int32_t)w >= 0) {
+                    uint32_t tmp;
+                    uint64_t saved;
+                    asm volatile(
+                        "s_mov_b64 %[sv], exec\n"
+                        "1:\n\t"
+                        "v_lshrrev_b32 %[nidx], 4, %[w]\n\t"
+                        "v_add_lshl_u32 %[off], %[nidx], %[c], 2\n\t"
+                        "buffer_load_dword %[w], %[off], %[rs], 0 offen\n\t"
+                        "s_add_i32 %[trips], %[trips], -1\n\t"
+                        "v_add_u32 %[sp], %[row], %[sp]\n\t"
+                        "v_add_f32 %[sh], -1.0, %[sh]\n\t"
+                        "v_bfe_u32 %[c], %[m0], %[sh], 1\n\t"
+                        "v_bfe_u32 %[t], %[m1], %[sh], 1\n\t"
+                        "v_lshl_or_b32 %[c], %[c], 1, %[t]\n\t"
+                        "v_bfe_u32 %[t], %[m2], %[sh], 1\n\t"
+                        "v_lshl_or_b32 %[c], %[c], 1, %[t]\n\t"
+                        "ds_write_b32 %[sp], %[nidx]\n\t"
+                        "s_cmp_eq_u32 %[trips], 0\n\t"
+                        "s_cbranch_scc1 2f\n\t"
+                        "s_waitcnt vmcnt(0)\n\t"
+                        "v_cmp_gt_i32 vcc, 0, %[w]\n\t"
+                        "s_andn2_b64 exec, exec, vcc\n\t"
+                        "s_cbranch_execnz 1b\n"
+                        "2:\n\t"
+                        "s_waitcnt vmcnt(0)\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [w] "+v"(w), [nidx] "+v"(nidx), [off] "+v"(off), [c] "+v"(c), [t] "=&v"(tmp), [sp] "+v"(sp), [sh] "+v"(sh),
+                          [trips] "+s"(trips), [sv] "=&s"(saved)
+                        : [m0] "v"(mu0), [m1] "v"(mu1), [m2] "v"(mu2), [rs] "s"(rs_asm), [row] "s"((uint32_t)(BLOCK * 4))
+                        : "vcc", "scc", "memory");
+                }
+            } else
             while ((int32_t)key >= 0 && (!kWalkTrips || trips != 0u)) {
                 if (kWalkTrips) trips -= 1u;
                 nidx = w >> 4;
                 sp += (uint32_t)(BLOCK * 4);
                 if (kWalkTrips) asm("" : "+v"(sp));  // (keeps the compiler from turning sp into base + a scalar: one more v_add per iteration)
                 lds_at(sp) = nidx;
+#if defined(SVO_DUMMY_WALK_S) || defined(SVO_DUMMY_WALK_F)
+                {
+#ifdef SVO_DUMMY_WALK_S
+                    for (int i_ = 0; i_ < SVO_DUMMY_WALK_S; i_++) { uint32_t t_; asm volatile("v_bfe_u32 %0, %1, 1, 30" : "=v"(t_) : "v"(mu0)); }
+#endif
+#ifdef SVO_DUMMY_WALK_F
+                    for (int i_ = 0; i_ < SVO_DUMMY_WALK_F; i_++) { uint32_t t_; asm volatile("v_add_f32 %0, 1.0, %1" : "=v"(t_) : "v"(mu0)); }
+#endif
+                }
+#endif
                 read_word();
             }
-            sh += 1u;  // back to the leaf's own bit
-            if (kWalkTrips) w = (int32_t)sh >= D - SMAX ? w : 0u;  // (signed: 2^D + code has no bits below level D, sh may have passed 0)
+            sh = __float_as_uint(__uint_as_float(sh) + 1.0f);  // back to the leaf's own bit
+            // (a word found below level SMAX -- the tree is deeper than declared -- ends the ray like the interior word the walk of rounds 1-3
+            // stopped at; compared as floats: sh may have passed 0)
+            const bool below = kWalkTrips && __uint_as_float(sh) < kMagic + (float)(D - SMAX);
+            if (kWalkTrips && !kWalkStops) w = below ? 0u : w;
             leaf_off = off;
             leaf_w = w;
             // ST_DESC -> ST_LEAF; or straight to ST_PENDING when the ray ends in this leaf (anything but an empty leaf: a solid one, or
             // an interior word at level SMAX) -- with live hit counters the step section has to see the lane once more (step 3a)
-            if (kWalkStops) stf *= ((w >> 4) != kVoxelOffset) ? 0.25f : 0.5f;
+            if (kWalkStops) stf *= ((w >> 4) != kVoxelOffset || below) ? 0.25f : 0.5f;
             else stf *= 0.5f;
             };
 
@@ -728,7 +794,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                 cam_mu2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mu2);
             }
             // worth it when the camera's leaf is deep (the copy at pick-up costs about two walk iterations)
-            cam_ok = (uint32_t)D - (uint32_t)__builtin_amdgcn_readfirstlane(sh) >= (uint32_t)(SBASE + 2);
+            cam_ok = (uint32_t)D - sh_of((uint32_t)__builtin_amdgcn_readfirstlane(sh)) >= (uint32_t)(SBASE + 2);
             stf = ST_IDLE;
         }
     }
@@ -909,7 +975,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                                 sh = cam_sh;
                                 mu0 = cam_mu0; mu1 = cam_mu1; mu2 = cam_mu2;
                             } else {
-                                const uint32_t sh0 = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 2), L0 = (uint32_t)D - sh0;
+                                const uint32_t sh0 = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 2), L0 = (uint32_t)D - sh_of(sh0);
                                 for (uint32_t l = 0; l < (uint32_t)NS && l + (uint32_t)SBASE <= L0; l++)
                                     lds[(uint32_t)SOFF + l * BLOCK + tid] = (uint32_t)__builtin_amdgcn_readlane((int)camv, (int)l);
                                 leaf_off = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS);
@@ -964,7 +1030,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             const bool at_leaf = sabs(stf) == ST_LEAF;
             const uint64_t c_c0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
             if (__ballot(at_leaf) != 0ull) {
-                const uint32_t L = min((uint32_t)D - sh, (uint32_t)SMAX);  // (a word below level SMAX ends the ray: the tree is deeper than declared)
+                const uint32_t L = min((uint32_t)D - sh_of(sh), (uint32_t)SMAX);  // (a word below level SMAX ends the ray: the tree is deeper than declared)
                 uint32_t todo = at_leaf ? (~satm & ((1u << L) - 2u)) : 0u;  // levels 1 .. L-1 not known to be saturated
                 constexpr uint32_t kTopLv = (2u << K) - 2u;  // levels 1 .. K
                 auto cell_k = [&]() -> uint32_t {
@@ -1016,13 +1082,13 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             if (!kWalkStops && (leaf_w >> 4) != kVoxelOffset) {
                 stf *= 0.5f;  // ST_LEAF -> ST_PENDING
             } else {
-                const float Hm = __builtin_amdgcn_ldexpf(0.5f, (int)sh);     // 2^(sh-1) = voxel_size / 2 in grid units (sh = D - L >= 1)
+                const float Hm = __uint_as_float((sh << 23) + 0x3F000000u);  // 2^(sh-1) = voxel_size / 2 in grid units (sh = D - L >= 1; the shift drops the magic's bits)
                 // leaf centre along one axis and a = (centre - pos) + r_sign * voxel_size / 2 (shader.wgsl:229): the code with its low sh
                 // bits replaced by 1 0 .. 0 is, read as a float, 2^23 + (lower corner + 2^(sh-1)); minus (2^23 + 2^22) that is the centre in
                 // grid units, exactly (the reference sums +-2^-k, which is exact too).  One instruction of the 4-cycle group per axis;
                 // the all-f32 form -- floor taken by the rounding of (U - (2^(sh-1) - 1/2)) + 3 * 2^(22+sh) -- costs four more of the
                 // other group and measured 2 % slower (profiles/r04_step_variants_ab.log)
-                const uint32_t keepm = 0xFFFFFFFFu << sh, hbit = __float_as_uint(kMagic + Hm);
+                const uint32_t keepm = 0xFFFFFFFFu << sh_of(sh), hbit = __float_as_uint(kMagic + Hm);
                 auto t_axis = [&](uint32_t mu, float P, float Dr, float Y, float S) -> float {
                     const float c = __uint_as_float((mu & keepm) | hbit) - (kMagic + kScale);
                     return div_by_recip(__builtin_fmaf(S, Hm, c - P), Dr, Y);
@@ -1072,11 +1138,14 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                     const uint32_t lbit = __float_as_uint(__builtin_fmaf(Hm, 2.0f, kMagic)) & ((1u << D) - 1u);  // 1 << sh
                     const uint32_t diff = ((mu0 ^ n0) | (mu1 ^ n1) | (mu2 ^ n2)) | lbit;
                     mu0 = n0; mu1 = n1; mu2 = n2;
-                    const uint32_t r = (uint32_t)__builtin_clz(diff) - (uint32_t)(31 - D);  // (diff != 0)
+#ifdef SVO_DUMMY_STEP_S
+                    for (int i_ = 0; i_ < SVO_DUMMY_STEP_S; i_++) { uint32_t t_; asm volatile("v_bfe_u32 %0, %1, 1, 30" : "=v"(t_) : "v"(mu0)); }
+#endif
+                    const uint32_t rb = (uint32_t)__builtin_clz(diff);  // r + (31 - D); diff != 0
                     if (CNT) {  // levels r and below belong to a new path
-                        satm &= (1u << r) - 1u;
+                        satm &= (1u << (rb - kRb)) - 1u;
                     }
-                    restart_at(r);
+                    restart_at_rb(rb);
                 }
             }
         }
