@@ -530,7 +530,13 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     uint32_t sh = __float_as_uint(kMagic + 1.0f), nidx = 0;
     auto sh_of = [](uint32_t shbits) -> uint32_t { return shbits & 31u; };
     constexpr uint32_t kShMagic = 0x4B000000u;  // bits of 2^23
-    uint32_t sp = ((uint32_t)SOFF + threadIdx.x) * 4u;  // LDS slot (byte offset) one row BELOW the walk's next push
+    // the lane's column of the ancestor stacks as ONE per-lane constant: byte address of row -(kRb + SBASE), so that row r - SBASE is
+    // colbase + (r + kRb) * 1024; every other per-lane LDS address is written as this one plus a constant (the counting instantiation
+    // has no register for a second one)
+    constexpr uint32_t kRb = (uint32_t)(31 - D);
+    constexpr uint32_t kRow = (uint32_t)(BLOCK * 4);
+    const uint32_t colbase = ((uint32_t)SOFF + threadIdx.x) * 4u - (kRb + (uint32_t)SBASE) * kRow;
+    uint32_t sp = colbase + (kRb + (uint32_t)SBASE) * kRow;  // LDS slot (byte offset) one row BELOW the walk's next push
     uint32_t leaf_off = 0, leaf_w = 0;  // current leaf: byte offset of its word, and the word
     auto sabs = [](float x) -> float { return SHD ? __builtin_fabsf(x) : x; };  // (only the SHD instantiation has negative states)
     constexpr bool kWalkStops = SVO_WALK_STOP != 0 && !CNT;
@@ -546,10 +552,9 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     auto lds_at = [&](uint32_t byte_offset) -> lds_u32 & { return *(lds_u32 *)(uintptr_t)byte_offset; };
     if (__builtin_amdgcn_groupstaticsize() != 0u) __builtin_trap();
     // rb = r + (31 - D): the step has r as a count of leading zeros, and every use of it here takes a constant anyway
-    constexpr uint32_t kRb = (uint32_t)(31 - D);
     auto restart_at_rb = [&](uint32_t rb) {
         const bool top = rb <= (uint32_t)(K + 1) + kRb;
-        sp = ((uint32_t)SOFF + tid) * 4u - (kRb + (uint32_t)SBASE) * (uint32_t)(BLOCK * 4) + rb * (uint32_t)(BLOCK * 4);  // stack[r - SBASE][lane], in bytes
+        sp = colbase + rb * kRow;  // stack[r - SBASE][lane], in bytes
         if (__ballot(top)) {  // wave-uniform: most rounds no lane crosses a level-(K+1) boundary
             const uint32_t cell = (__builtin_amdgcn_ubfe(mu0, D - K, K) << (2 * K)) | (__builtin_amdgcn_ubfe(mu1, D - K, K) << K) |
                                   __builtin_amdgcn_ubfe(mu2, D - K, K);
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             sh = (kShMagic + (uint32_t)(D + 1)) - (top ? (e >> 27) : rb - kRb);
             nidx = e & 0x07FFFFFFu;
             // a walk from the table starts at level K+1 or above: its first push (if any) is the group of level K+2, row 0
-            sp = top ? ((uint32_t)SOFF + tid) * 4u - (uint32_t)(BLOCK * 4) : sp;
+            sp = top ? colbase + (kRb + (uint32_t)SBASE - 1u) * kRow : sp;
         } else {  // a stack entry is the child group itself (< 2^27): nothing to unpack; the walk's first push goes to the row of level r + 1
             sh = (kShMagic + (uint32_t)(D + 1) + kRb) - rb;
             nidx = lds_at(sp);
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             stf = ST_DESC;
             restart_at(1u);
             descend();
-            uint32_t v = lane < (uint32_t)NS ? lds[(uint32_t)SOFF + lane * BLOCK + tid] : 0u;  // row `lane` of this lane's own column
+            uint32_t v = lane < (uint32_t)NS ? (uint32_t)lds_at(colbase + (kRb + (uint32_t)SBASE + lane) * kRow) : 0u;  // row `lane` of this lane's own column
             v = lane == (uint32_t)NS ? leaf_off : v;
             v = lane == (uint32_t)NS + 1u ? leaf_w : v;
             v = lane == (uint32_t)NS + 2u ? sh : v;  // (D - the leaf's level)
@@ -969,7 +974,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                             // a ray from the camera's own position: the walk the wave made at the start (see above), path codes included
                             if (kCamScalar) {
 #pragma unroll
-                                for (int l = 0; l < NS; l++) lds[(uint32_t)SOFF + l * BLOCK + tid] = cam_rows[l];  // (rows below the leaf: never read)
+                                for (int l = 0; l < NS; l++) lds_at(colbase + (kRb + (uint32_t)SBASE + (uint32_t)l) * kRow) = cam_rows[l];  // (rows below the leaf: never read)
                                 leaf_off = cam_leaf_off;
                                 leaf_w = cam_leaf_w;
                                 sh = cam_sh;
@@ -977,7 +982,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                             } else {
                                 const uint32_t sh0 = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 2), L0 = (uint32_t)D - sh_of(sh0);
                                 for (uint32_t l = 0; l < (uint32_t)NS && l + (uint32_t)SBASE <= L0; l++)
-                                    lds[(uint32_t)SOFF + l * BLOCK + tid] = (uint32_t)__builtin_amdgcn_readlane((int)camv, (int)l);
+                                    lds_at(colbase + (kRb + (uint32_t)SBASE + l) * kRow) = (uint32_t)__builtin_amdgcn_readlane((int)camv, (int)l);
                                 leaf_off = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS);
                                 leaf_w = (uint32_t)__builtin_amdgcn_readlane((int)camv, NS + 1);
                                 sh = sh0;
@@ -1053,7 +1058,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                     const uint32_t kk = l - 1u, shc = (uint32_t)D - kk;
                     uint32_t g = 0u;
                     if (l >= (uint32_t)SBASE) {
-                        g = lds[(uint32_t)SOFF + (l - (uint32_t)SBASE) * BLOCK + tid];
+                        g = lds_at(colbase + (l + kRb) * kRow);
                     } else if (l >= 2u) {
                         const uint32_t cell = (__builtin_amdgcn_ubfe(mu0, shc, kk) << (2u * kk)) | (__builtin_amdgcn_ubfe(mu1, shc, kk) << kk) | __builtin_amdgcn_ubfe(mu2, shc, kk);
                         g = kk == (uint32_t)K ? (tbl[cell] & 0x07FFFFFFu) : aux[(kk == 1u ? 0u : 8u) + cell];
