@@ -31,7 +31,7 @@
 #ifndef SVO_WALK_TRIPS   // 1: the walk's depth limit is a count of its iterations (wave-uniform) instead of a test of every lane's level
 #define SVO_WALK_TRIPS 1
 #endif
-#ifndef SVO_WALK_ASM   // 1: the walk's loop hand-written (default instantiation): what follows a word's arrival is a compare, one scalar
+#ifndef SVO_WALK_ASM   // 1: the walk's loop hand-written (all but the timeline build): what follows a word's arrival is a compare, one scalar
 #define SVO_WALK_ASM 1  // instruction on the execute mask and the branch
 #endif
 #ifndef SVO_CAM_SCALAR
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     auto sabs = [](float x) -> float { return SHD ? __builtin_fabsf(x) : x; };  // (only the SHD instantiation has negative states)
     constexpr bool kWalkStops = SVO_WALK_STOP != 0 && !CNT;
     constexpr bool kWalkTrips = SVO_WALK_TRIPS != 0;
-    constexpr bool kWalkAsm = SVO_WALK_ASM != 0 && kWalkTrips && !CNT && !DBG;
+    constexpr bool kWalkAsm = SVO_WALK_ASM != 0 && kWalkTrips && !DBG;
     uint32_t satm = 0;                // CNT: bit l = the word of level l on the lane's current path is known to be saturated (step 3a)
 
     // (re)start a descent: from the LDS top table when the restart level r is at most K+1 (the table also
@@ -695,7 +695,47 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                 // The same loop as below, instruction for instruction, but for its control: the compiler keeps the lanes that have
                 // left in a second mask and folds the count's flag into it -- four scalar instructions between a word's arrival
                 // and the next load; every instruction there costs the walk its latency (profiles/r04_walk_critical_path_ab.log).
-                if ((int32_t)w >= 0) {
+                if (CNT && (int32_t)w >= 0) {
+                    // (hit counters live: an interior word whose counter has reached 15 is noted in satm, bit = its level, while the
+                    // next word travels -- only the counter bits are taken before the load is issued; the word that ends the walk
+                    // needs no note: step 3a looks at the leaf's own counter, and bit L is cleared by every restart before it is read)
+                    uint32_t tmp, cnt4;
+                    uint64_t saved;
+                    asm volatile(
+                        "s_mov_b64 %[sv], exec\n"
+                        "1:\n\t"
+                        "v_and_b32 %[t2], 15, %[w]\n\t"
+                        "v_lshrrev_b32 %[nidx], 4, %[w]\n\t"
+                        "v_add_lshl_u32 %[off], %[nidx], %[c], 2\n\t"
+                        "buffer_load_dword %[w], %[off], %[rs], 0 offen\n\t"
+                        "s_add_i32 %[trips], %[trips], -1\n\t"
+                        "v_cmp_eq_u32 vcc, 15, %[t2]\n\t"
+                        "v_sub_u32 %[t], %[dm1], %[sh]\n\t"
+                        "v_cndmask_b32_e64 %[t2], 0, 1, vcc\n\t"
+                        "v_lshlrev_b32 %[t2], %[t], %[t2]\n\t"
+                        "v_or_b32 %[satm], %[satm], %[t2]\n\t"
+                        "v_add_u32 %[sp], %[row], %[sp]\n\t"
+                        "v_add_f32 %[sh], -1.0, %[sh]\n\t"
+                        "v_bfe_u32 %[c], %[m0], %[sh], 1\n\t"
+                        "v_bfe_u32 %[t], %[m1], %[sh], 1\n\t"
+                        "v_lshl_or_b32 %[c], %[c], 1, %[t]\n\t"
+                        "v_bfe_u32 %[t], %[m2], %[sh], 1\n\t"
+                        "v_lshl_or_b32 %[c], %[c], 1, %[t]\n\t"
+                        "ds_write_b32 %[sp], %[nidx]\n\t"
+                        "s_cmp_eq_u32 %[trips], 0\n\t"
+                        "s_cbranch_scc1 2f\n\t"
+                        "s_waitcnt vmcnt(0)\n\t"
+                        "v_cmp_gt_i32 vcc, 0, %[w]\n\t"
+                        "s_andn2_b64 exec, exec, vcc\n\t"
+                        "s_cbranch_execnz 1b\n"
+                        "2:\n\t"
+                        "s_waitcnt vmcnt(0)\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [w] "+v"(w), [nidx] "+v"(nidx), [off] "+v"(off), [c] "+v"(c), [t] "=&v"(tmp), [t2] "=&v"(cnt4), [sp] "+v"(sp), [sh] "+v"(sh),
+                          [satm] "+v"(satm), [trips] "+s"(trips), [sv] "=&s"(saved)
+                        : [m0] "v"(mu0), [m1] "v"(mu1), [m2] "v"(mu2), [rs] "s"(rs_asm), [row] "s"((uint32_t)(BLOCK * 4)), [dm1] "s"((uint32_t)(D - 1))
+                        : "vcc", "scc", "memory");
+                } else if (!CNT && (int32_t)w >= 0) {
                     uint32_t tmp;
                     uint64_t saved;
                     asm volatile(
