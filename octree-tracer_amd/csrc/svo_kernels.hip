@@ -270,15 +270,18 @@ __global__ __launch_bounds__(256) void build_top_table_kernel(const uint32_t *no
 // kernel of rounds 1-3 did five sixths of its work.  So everything the DDA step needs is now derived in f32, exactly:
 //   * a path code U (D = 23 bits) lives in a register as the bits of the float 2^23 + U, which IS 0x4B000000 | U: the walk
 //     extracts child bits from it, the step subtracts 2^23 and has U as a float;
-//   * the leaf centre is  floor(U / 2^s) 2^s + 2^(s-1) - 2^22  with the floor taken by the rounding of an addition:
-//     (U - (2^(s-1) - 1/2)) + 3 2^(22+s) lands on the multiple of 2^s below U + 1/2 (never a tie), all operands exact;
-//   * the tie mask  t_i == min  is  1 - clamp(clamp((t_i - min) 2^126) 2^24)  (a difference of two floats is 0 or at
-//     least 2^-149), the nudge  mask * copysign(k, dir)  one fma with it, the mask bits a sum of them;
+//   * the leaf centre: the code with its low s bits replaced by 1 0 .. 0 (one and-or) is, read as a float, 2^23 + centre + 2^22;
+//   * the tie mask  t_i == min  selects the nudge k or 0 (compare + select; as  1 - clamp(clamp((t_i - min) 2^126) 2^24)  it needs no
+//     compare, same time), the nudge  k_i * copysign(1, dir)  is one fma with it, the mask bits a sum of the k_i;
 //   * in_bounds is a product of six clamps (a coordinate is a float: below 2^22 it is at most 2^22 - 1/4, so
 //     clamp(4 (2^22 - g)) is exactly 1 or 0), the step limit one more factor, and ONE compare decides who goes on;
-//   * steps, mask and lane state are floats; the state changes by multiplication (svo_trace_fn.h).
+//   * steps, mask, lane state and the leaf's level (sh) are floats; the state changes by multiplication (svo_trace_fn.h).
 // What stays in the other group: floor() of the three new coordinates, the xor / or3 / count-leading-zeros that finds the
-// restart level, one ldexp, min3, four compares -- 20 instead of 75 per round.
+// restart level, three and-ors, min3, the tie compares and selects -- 22 instead of 75 per round.
+// And the walk is written for where its instructions stand: a wave that has waited for a word re-enters the SIMD's
+// rotation among seven, so every instruction between the word's arrival and the next load costs about one rotation (2 % of the
+// frame each), those issued while a load is in flight nearly nothing.  Its loop is hand-written: compare, s_andn2 exec, branch,
+// shift, shift-add, load; child index of the next level, push, level counter and the depth limit (an iteration count) in the shadow.
 // The kernel's first argument, re-read from the kernarg segment where it is needed: ray generation and the record writes use
 // some sixty scalar values (the uniforms, the work description, five pointers) that the hot loop never touches; read through
 // the by-value parameter they would be loaded once and stay in scalar registers for the whole kernel, which has none to spare --
