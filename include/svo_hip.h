@@ -107,7 +107,7 @@ typedef enum svo_option {
     SVO_OPT_TREE_DEPTH = 9,  /* upper bound of the octree depth (Settings.octree_depth, app.rs:24); default 16.
                                 <= 16: default kernel; <= 22: deep-stack kernel (the STACK variant's 23-bit path codes resolve 22 levels; it was 23 up to
                                 round 3); above: the general RESTART kernel.  A tree deeper than the bound given here is refused: the launch
-                                completes, svo_sync returns SVO_ERR_DEPTH-class failure and the frame's records are not to be used
+                                completes, svo_sync returns SVO_ERR_STATE (svo_last_error says so) and the frame's records are not to be used
                                 (tests/test_parity_gpu.py: test_tree_deeper_than_declared_is_refused) */
     SVO_OPT_BLOCK_SHAPE = 10, /* log2 of the width of the 64-pixel blocks a wave works on (3: 8x8, 4: 16x4, ...) */
     SVO_OPT_DEBUG_BUFFER = 7, /* device pointer receiving 16 words per wave: start, queue-dry, end (10 ns ticks), rounds, ...,

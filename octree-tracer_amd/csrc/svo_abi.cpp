@@ -686,8 +686,8 @@ int svo_sync(svo_ctx *ctx) {
     if (st & 1u) {
         HIP_TRY(ctx, hipMemset(ctx->status, 0, sizeof(uint32_t)));
         return fail(ctx, SVO_ERR_STATE,
-                    "octree deeper than the STACK variant resolves (rays report the step-limit sentinel); "
-                    "use SVO_VARIANT_RESTART for such trees");
+                    "octree deeper than SVO_OPT_TREE_DEPTH declares (the frame's records are not valid); "
+                    "raise SVO_OPT_TREE_DEPTH (above 22: the general kernel) or use SVO_VARIANT_RESTART");
     }
     return SVO_OK;
 }
