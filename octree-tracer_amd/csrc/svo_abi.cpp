@@ -183,16 +183,26 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
             if (sc.cost) (void)hipFree(sc.cost);
             if (sc.cls_now) (void)hipFree(sc.cls_now);
             if (sc.order) (void)hipFree(sc.order);
+            if (sc.balance) (void)hipFree(sc.balance);
             sc = svo_ctx::Sched{};
             size_t want = n_strips < 4096 ? 4096 : n_strips;
             HIP_TRY(ctx, hipMalloc((void **)&sc.cost, want + 32 + svo::kOrderHistWords * sizeof(uint32_t)));
             HIP_TRY(ctx, hipMalloc((void **)&sc.cls_now, want + 32 + svo::kOrderHistWords * sizeof(uint32_t)));
-            HIP_TRY(ctx, hipMalloc((void **)&sc.order, (want + 8 * (svo::kCostClasses + 8) + 8) * sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMalloc((void **)&sc.order, (2 * want + 8 * (svo::kCostClasses + 8) + 8) * sizeof(uint32_t)));  // (8 lists of order_list_cap entries)
+            HIP_TRY(ctx, hipMalloc((void **)&sc.balance, svo::kBalanceWords * sizeof(uint32_t)));
             sc.cap = want;
         }
         // costs and order are only meaningful for the same work layout (same pixels behind every strip)
         if (sc.valid && memcmp(&sc.key, &wd, sizeof(wd)) != 0) sc.valid = false;
-        a.order_cap = (n_strips + 7u) / 8u + svo::kCostClasses;  // a list holds ceil(n_class / 8) strips of each of the cost classes
+        if (!sc.valid) {  // a new layout starts from equal shares of the lists
+            uint32_t init[svo::kBalanceWords] = {};
+            for (uint32_t k = 0; k <= 8; k++) init[k] = k * 8192u;
+            init[9] = 0xFFFFFFFFu;
+            HIP_TRY(ctx, hipMemcpyAsync(sc.balance, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+            sc.balance_frames = 0;
+        }
+        a.balance = ctx->list_balance ? sc.balance : nullptr;
+        a.order_cap = svo::order_list_cap(wd, n_strips);
         if (filtered) {
             // slots without a ray (secondary rays of pixels that hit nothing): this frame's lists leave out the strips
             // that consist of nothing else, ordered by the costs of an earlier frame when there are any
@@ -254,13 +264,18 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         const bool same_input = (wd.mode != 2 || opt.sched_slot == 1) && sc.built_nodes_version == ctx->store->version &&
                                 memcmp(&sc.built_uniforms, &ctx->uniforms, sizeof(svo_uniforms)) == 0 && sc.age < 64;
         const bool moving = sc.have_prev && memcmp(&sc.prev_uniforms, &ctx->uniforms, sizeof(svo_uniforms)) != 0;
+        // (a frame traced with complete lists also feeds the time its lists took back into their shares: while camera and tree stay
+        // put the lists are rebuilt for the first sixteen such frames, then the shares have settled)
+        const bool fed_back = a.balance != nullptr && a.order != nullptr && !filtered;
         const bool rebuild = schedule && (!sc.valid || (sc.order_filtered && !filtered) || (!same_input && sc.age + 1 >= ctx->sched_period) ||
-                                          (same_input && sc.floored && !moving));
+                                          (same_input && sc.floored && !moving) || (same_input && fed_back && sc.balance_frames < 16u));
         // a camera in motion: strips near the long ones of this frame are not scheduled as cheap (strip_danger_kernel)
         const bool floor_now = rebuild && !filtered && moving && ctx->motion_floor != 0u && wd.mode == 0 && wd.n_rects == 1u;
         // (a launch with a skip mask builds its lists before the trace, every frame: here only the costs are measured)
-        HIP_TRY(ctx, svo::launch_post(a, li, rebuild ? sc.cost : nullptr, sc.order, n_strips, (n_strips + 7u) / 8u + svo::kCostClasses,
-                                      rebuild && !filtered, ctx->stream, floor_now ? sc.cls_now : nullptr, ctx->motion_floor));
+        HIP_TRY(ctx, svo::launch_post(a, li, rebuild ? sc.cost : nullptr, sc.order, n_strips, svo::order_list_cap(wd, n_strips),
+                                      rebuild && !filtered, ctx->stream, floor_now ? sc.cls_now : nullptr, ctx->motion_floor,
+                                      (fed_back && (!same_input || sc.balance_frames < 16u)) ? sc.balance_frames + 1u : 0u));
+        if (fed_back) sc.balance_frames++;
         if (rebuild && !filtered) sc.floored = floor_now;
         sc.prev_uniforms = ctx->uniforms;
         sc.have_prev = true;

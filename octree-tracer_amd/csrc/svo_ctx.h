@@ -1,6 +1,7 @@
 // svo_ctx.h -- the device context behind the opaque `svo_ctx` of include/svo_hip.h; shared by svo_abi.cpp (trace / scan
 // dispatch) and svo_comm.cpp (RCCL frame gather).  Internal: not part of the boundary.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -71,6 +72,8 @@ struct svo_ctx {
         uint8_t *cost = nullptr;
         uint8_t *cls_now = nullptr;  // launches with a skip mask: this frame's classes (0xFF = strip without a ray)
         uint32_t *order = nullptr;
+        uint32_t *balance = nullptr;  // kBalanceWords: the lists' shares and the stamps they follow (svo_kernels.hip: balance_step)
+        uint32_t balance_frames = 0;  // scheduled frames of this layout whose stamps have been fed back
         size_t cap = 0;
         bool valid = false;
         bool order_filtered = false;  // `order` was built for one frame without its empty / culled strips: not a general schedule
@@ -86,6 +89,7 @@ struct svo_ctx {
         bool floored = false;
     };
     Sched sched[2];
+    bool list_balance = getenv("SVO_NO_LIST_BALANCE") == nullptr;  // (A/B switch of the list-share feedback, svo_kernels.hip: balance_step)
     uint32_t motion_floor = 0x1204;  // SVO_OPT_SCHEDULE_MOTION: class floor | radius << 8 | min_count << 12; 0 = off
     bool schedule = true;
     uint32_t sched_period = 2;  // frames between schedule rebuilds (tools/perf_probe.py --motion: 2 keeps the gain under camera motion)

@@ -55,6 +55,8 @@ struct TraceArgs {
     uint32_t order_cap;         // entries reserved per list
     uint32_t *debug;            // optional: 16 words per wave (start, queue-dry, end ticks of 10 ns, rounds, active-lane sum, ..., phase cycles)
     const uint8_t *skip;        // mode 2, optional: one byte per ray; non-zero = no ray here, its (all-zero) record is already written
+    uint32_t *balance;          // STACK, optional: kBalanceWords words of the schedule's list-share feedback (see launch_post); the trace kernel
+                                // records when its first wave started ([9], min) and when a sample of every list's workgroups ended, 10 ns ticks
     svo_hit *shadow_hits;       // STACK, optional (fused shadow rays): the lane that finishes a primary ray with a hit goes on with that
                                 // pixel's shadow ray (shader.wgsl:275-280) and writes its record here; pixels without one get zeros
 };
@@ -83,8 +85,16 @@ constexpr uint32_t kMaxScheduledStrips = 1u << 20;  // (2^26 items / 64)
 // class in screen order; the finer classes end the lists with the strips that really are the shortest
 constexpr uint32_t kCostShift = 2, kCostClasses = 32;
 constexpr uint32_t kOrderHistWords = 64 * kCostClasses;  // chunk histograms of the schedule builder, stored behind the class bytes
+// list-share feedback of a schedule: [0..8] cumulative shares of the 8 lists (16-bit fractions, [0] = 0, [8] = 65536), [9]
+// the last scheduled frame's start stamp, [18] updates so far; behind them (kBalanceHead) kBalanceSlots end stamps: slot i * 8 + l =
+// the i-th sampled workgroup of list l (every kBalanceEvery-th of the list's workgroups stores one; room for 4096 workgroups)
+constexpr uint32_t kBalanceHead = 32, kBalanceEvery = 1, kBalanceSlots = 8 * 512, kBalanceWords = kBalanceHead + kBalanceSlots;
+// entries reserved per list of a schedule: a list holds its share of every cost class -- an eighth, or what the feedback gives it
+// (at most twice that)
+inline uint32_t order_list_cap(const WorkDesc &, uint32_t n_strips) { return (n_strips + 3u) / 4u + kCostClasses; }
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
-                       uint32_t cap, bool build_schedule, hipStream_t stream, uint8_t *moved = nullptr, uint32_t motion_floor = 0);
+                       uint32_t cap, bool build_schedule, hipStream_t stream, uint8_t *moved = nullptr, uint32_t motion_floor = 0,
+                       uint32_t balance_update = 0);
 
 // explicit rays with a skip mask: this frame's strip lists without the strips that hold no ray (classes from `prev`, or screen order)
 hipError_t launch_schedule_skipping(const uint8_t *skip, uint32_t n_items, const uint8_t *prev, uint8_t *cls, uint32_t *sched,

@@ -34,6 +34,12 @@
 #ifndef SVO_WALK_ASM   // 1: the walk's loop hand-written (all but the timeline build): what follows a word's arrival is a compare, one scalar
 #define SVO_WALK_ASM 1  // instruction on the execute mask and the branch
 #endif
+#ifndef SVO_WALK_LUT   // 1: the walk takes the child indices of six levels at a time from one register built with three LDS look-ups (a 64-entry
+#define SVO_WALK_LUT 2  // bit-spreading table) instead of three bit-field extracts and two shift-ors per level (default kernel, static tree)
+#endif
+#ifndef SVO_DBG_LIGHT   // 1: the timeline instantiation records only its time stamps (start, loop entry, generations, dry, end) and runs the
+#define SVO_DBG_LIGHT 0  // product's hand-written walk at the product's occupancy: a progress curve that is not distorted by the phase clocks
+#endif
 #ifndef SVO_CAM_SCALAR
 #define SVO_CAM_SCALAR 0
 #endif
@@ -295,15 +301,20 @@ __device__ __forceinline__ const TraceArgs &fresh_args() {
 
 // CNT: hit counters live (adaptive mode, shader.wgsl:157-161), see step 3a in the loop.
 template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD>
-__global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT : ((SHD || DBG) ? 6 : SVO_WAVES_PER_SIMD))) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
+__global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT : ((SHD || (DBG && SVO_DBG_LIGHT == 0)) ? 6 : SVO_WAVES_PER_SIMD))) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
                                                                uint32_t *work_counter, uint32_t *defer) {
+    constexpr bool DBGH = DBG && SVO_DBG_LIGHT == 0;  // the timeline build's phase clocks and tallies (the light build keeps the time stamps only)
     constexpr int D = kPathBits;
     constexpr int SBASE = K + 2;       // first level kept on the LDS stack
     constexpr int SMAX = K + 1 + NS;   // last level kept on the LDS stack = deepest level resolved
     static_assert(SMAX <= D - 1, "stack deeper than the path codes");
     constexpr int TBL = 1 << (3 * K);
     constexpr bool kTopInLds = SVO_TOP_IN_LDS != 0;
-    constexpr int TOFF = kTopInLds ? TBL : 0;  // LDS words in front of the ray pools
+    // the walk's bit-spreading table (64 words, see descend()): behind the top table, in every instantiation (the host's lds_bytes counts it)
+    constexpr int kLutWords = 64;
+    constexpr int LOFF = kTopInLds ? TBL : 0;
+    constexpr int TOFF = LOFF + kLutWords;  // LDS words in front of the ray pools
+    constexpr bool kLut = SVO_WALK_LUT != 0 && NS <= 12 && !CNT;
     // The ancestor stacks come LAST in the workgroup's LDS: the walk below does not check the level it has reached (two instructions
     // per word), so in a tree deeper than the caller declared a lane pushes rows that do not exist -- beyond the allocation, where
     // the hardware drops the write (and reads return 0: tools/experiments/lds_oob_probe.hip) instead of into another ray's data.
@@ -440,10 +451,10 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
         const uint64_t m = __ballot(n != 0u);
         if (!m) return;
         if (cq_n > (uint32_t)kCountQueue - 64u) {
-            if (DBG) dbg_desc_rounds += 1u;  // (CNT: slot 14 = queue flushes, slot 13 = cycles in them)
-            const uint64_t c_f0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
+            if (DBGH) dbg_desc_rounds += 1u;  // (CNT: slot 14 = queue flushes, slot 13 = cycles in them)
+            const uint64_t c_f0 = DBGH ? __builtin_amdgcn_s_memtime() : 0ull;
             cq_flush();
-            if (DBG && lane == 0u) dbg_desc_lanes += (uint32_t)(__builtin_amdgcn_s_memtime() - c_f0);
+            if (DBGH && lane == 0u) dbg_desc_lanes += (uint32_t)(__builtin_amdgcn_s_memtime() - c_f0);
         }
         if (n) cq[cq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = p | (min(n, 15u) << 27);
         cq_n += (uint32_t)__popcll(m);
@@ -451,8 +462,14 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
 
     if (kTopInLds) {
         for (uint32_t i = tid; i < (uint32_t)TBL; i += BLOCK) lds[i] = a.top_table[i];
-        __syncthreads();
     }
+    if (kLut && tid < (uint32_t)kLutWords) {  // entry v: bit j of v moved to bit 3 j, as a float (the three axes are combined by two fmas)
+        uint32_t sp3 = 0u;
+#pragma unroll
+        for (int j = 0; j < 6; j++) sp3 |= ((tid >> j) & 1u) << (3 * j);
+        lds[LOFF + tid] = __float_as_uint((float)sp3);
+    }
+    if (kTopInLds || kLut) __syncthreads();
 
     const uint32_t n_items = a.work.n_items;
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane((blockIdx.x * BLOCK + tid) >> 6);
@@ -510,11 +527,11 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     }
     uint32_t pool_n = 0, pool_i = 0;  // wave-uniform: rays waiting in the pool, index of the first
     // optional per-wave timeline (diagnostic builds of the host set a.debug): start, queue-dry, end in 10 ns ticks
-    uint64_t t_begin = 0, t_dry = 0;
+    uint32_t t_begin = 0, t_dry = 0;
     uint32_t n_rounds = 0, dbg_active = 0, dbg_iters = 0, dbg_refills = 0, dbg_gens = 0;
     // phase clocks of the timeline build (shader cycles, s_memtime): refill / descent / step, and the descent's shape
     uint64_t c_mark = 0;
-    if (DBG) t_begin = __builtin_amdgcn_s_memrealtime();
+    if (DBG) t_begin = (uint32_t)__builtin_amdgcn_s_memrealtime();
 
     // per-lane ray state
     float stf = ST_IDLE;              // see ST_* (svo_trace_fn.h); negative: a shadow ray (SHD)
@@ -544,7 +561,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     auto sabs = [](float x) -> float { return SHD ? __builtin_fabsf(x) : x; };  // (only the SHD instantiation has negative states)
     constexpr bool kWalkStops = SVO_WALK_STOP != 0 && !CNT;
     constexpr bool kWalkTrips = SVO_WALK_TRIPS != 0;
-    constexpr bool kWalkAsm = SVO_WALK_ASM != 0 && kWalkTrips && !DBG;
+    constexpr bool kWalkAsm = SVO_WALK_ASM != 0 && kWalkTrips && !DBGH;
     uint32_t satm = 0;                // CNT: bit l = the word of level l on the lane's current path is known to be saturated (step 3a)
 
     // (re)start a descent: from the LDS top table when the restart level r is at most K+1 (the table also
@@ -653,7 +670,37 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             // sh -= 1, then the child the position selects at the level of that bit: x << 2 | y << 1 | z.  Three-operand forms the
             // compiler does not pick by itself, in ONE asm statement (the compiler pads every inline-asm statement with an s_nop, and
             // keeping the decrement inside saves a copy of the counter)
+            // kLut (round 5): those five instructions of the 4-cycle group, once per level and lane, were a third of the walk's issue cycles.
+            // The child indices of SIX levels are taken at once instead: the six code bits of every axis below the restart level index a
+            // 64-entry LDS table that spreads them to every third bit (as a float), m = 4 sx + 2 sy + sz + 2^23 is two fmas and an add of
+            // the 2-cycle group, and a level's child index is ONE bit-field extract of m at a wave-uniform position (the lanes of a walk
+            // start at different levels but advance together).  Six levels later (one walk in a hundred) the look-up is repeated.
+            // First code bit wanted = sh - 1 >= D - SMAX = 7, so the table offset (code >> (sh - 8)) & 0xFC needs no left shift.
+            uint32_t m = 0u;
+            int32_t pos = 0;  // wave-uniform: bit position in m of the child index worked out last
+            auto lut_fetch = [&](float first_bit_minus_7) {  // (as the bits of 2^23 + that number: a shift amount is read from the low five bits)
+                const uint32_t k = __float_as_uint(first_bit_minus_7);
+                const float fx = __uint_as_float(lds_at((uint32_t)LOFF * 4u + ((mu0 >> (k & 31u)) & 0xFCu)));
+                const float fy = __uint_as_float(lds_at((uint32_t)LOFF * 4u + ((mu1 >> (k & 31u)) & 0xFCu)));
+                const float fz = __uint_as_float(lds_at((uint32_t)LOFF * 4u + ((mu2 >> (k & 31u)) & 0xFCu)));
+                m = __float_as_uint(__builtin_fmaf(fx, 4.0f, __builtin_fmaf(fy, 2.0f, fz + kMagic)));
+            };
+            constexpr bool kLutLate = SVO_WALK_LUT == 2;  // the first word's child the old way, the look-up in the shadow of the first load
+            if (kLut && !kLutLate) {
+                lut_fetch(__uint_as_float(sh) - 8.0f);
+                pos = 18;
+            }
+            bool first_child = true;
             auto child_below = [&]() -> uint32_t {
+                if (kLut && !(kLutLate && first_child)) {
+                    sh = __float_as_uint(__uint_as_float(sh) - 1.0f);
+                    pos -= 3;
+                    if (pos < 0) {
+                        lut_fetch(__uint_as_float(sh) - 7.0f);  // (sh is the bit of the level whose child is wanted now)
+                        pos = 15;
+                    }
+                    return __builtin_amdgcn_ubfe(m, (uint32_t)pos, 3u);
+                }
                 uint32_t c, tmp;
                 asm("v_add_f32 %2, -1.0, %2\n\t"
                     "v_bfe_u32 %0, %3, %2, 1\n\t"
@@ -666,7 +713,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                 return c;
             };
             auto tally = [&]() {
-                if (DBG) {
+                if (DBGH) {
                     const uint64_t in_loop = __ballot(true);
                     if (lane == (uint32_t)__ffsll((unsigned long long)in_loop) - 1u) {  // (tallies summed over lanes at the end)
                         if (!CNT) dbg_desc_iters += 1u;
@@ -678,12 +725,22 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             // pushed for it.  (2) While a word travels the child index of the NEXT level is worked out -- it depends on the position
             // only -- so that between a word's arrival and the next load stand a shift and an add instead of eight instructions.
             uint32_t c = child_below();
+            first_child = false;
+            bool first_word = true;
             auto read_word = [&]() {
                 tally();
                 off = (nidx + c) << 2;
                 w = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
+                if (kLut && kLutLate && first_word) {
+                    __builtin_amdgcn_sched_barrier(0);  // (the look-up's address arithmetic behind the load, not in front of it)
+                    lut_fetch(__uint_as_float(sh) - 7.0f);  // (sh is the bit of the word in flight: the first of the six)
+                    asm volatile("" : "+v"(m));  // (here, under the load -- the compiler would sink it behind the wait for the word)
+                    pos = 15;
+                }
+                first_word = false;
                 if (CNT) satm |= ((w & 15u) == 15u ? 1u : 0u) << (((uint32_t)D - sh_of(sh)) & 31u);  // (a counter never goes down within a frame)
                 c = child_below();  // (sh now points one level below the word in flight)
+                if (kLut) asm volatile("" : "+v"(c));  // (before the wait for the word, not behind it)
                 // sign bit: a leaf (word >= VOXEL_OFFSET << 4), or level SMAX reached (deeper trees are refused)
                 key = kWalkTrips ? w : (w | (sh_of(sh) - (uint32_t)(D - SMAX)));
             };
@@ -737,6 +794,57 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                         : [w] "+v"(w), [nidx] "+v"(nidx), [off] "+v"(off), [c] "+v"(c), [t] "=&v"(tmp), [t2] "=&v"(cnt4), [sp] "+v"(sp), [sh] "+v"(sh),
                           [satm] "+v"(satm), [trips] "+s"(trips), [sv] "=&s"(saved)
                         : [m0] "v"(mu0), [m1] "v"(mu1), [m2] "v"(mu2), [rs] "s"(rs_asm), [row] "s"((uint32_t)(BLOCK * 4)), [dm1] "s"((uint32_t)(D - 1))
+                        : "vcc", "scc", "memory");
+                } else if (kLut && (int32_t)w >= 0) {
+                    // (the loop of the next branch with the child index taken from m: one bit-field extract at the scalar position pos;
+                    // label 3 is the table look-up for the next six levels, taken when pos runs out -- in the shadow of the load like the rest)
+                    uint32_t tmp;
+                    uint64_t saved;
+                    asm volatile(
+                        "s_mov_b64 %[sv], exec\n"
+                        "1:\n\t"
+                        "v_lshrrev_b32 %[nidx], 4, %[w]\n\t"
+                        "v_add_lshl_u32 %[off], %[nidx], %[c], 2\n\t"
+                        "buffer_load_dword %[w], %[off], %[rs], 0 offen\n\t"
+                        "s_add_i32 %[trips], %[trips], -1\n\t"
+                        "v_add_u32 %[sp], %[row], %[sp]\n\t"
+                        "v_add_f32 %[sh], -1.0, %[sh]\n\t"
+                        "s_add_i32 %[pos], %[pos], -3\n\t"
+                        "s_cmp_lt_i32 %[pos], 0\n\t"
+                        "s_cbranch_scc1 3f\n"
+                        "4:\n\t"
+                        "v_bfe_u32 %[c], %[m], %[pos], 3\n\t"
+                        "ds_write_b32 %[sp], %[nidx]\n\t"
+                        "s_cmp_eq_u32 %[trips], 0\n\t"
+                        "s_cbranch_scc1 2f\n\t"
+                        "s_waitcnt vmcnt(0)\n\t"
+                        "v_cmp_gt_i32 vcc, 0, %[w]\n\t"
+                        "s_andn2_b64 exec, exec, vcc\n\t"
+                        "s_cbranch_execnz 1b\n\t"
+                        "s_branch 2f\n"
+                        "3:\n\t"
+                        "v_add_f32 %[m], 0xc0e00000, %[sh]\n\t"
+                        "v_lshrrev_b32 %[c], %[m], %[m0]\n\t"
+                        "v_lshrrev_b32 %[t], %[m], %[m1]\n\t"
+                        "v_lshrrev_b32 %[m], %[m], %[m2]\n\t"
+                        "v_and_b32 %[c], 0xfc, %[c]\n\t"
+                        "v_and_b32 %[t], 0xfc, %[t]\n\t"
+                        "v_and_b32 %[m], 0xfc, %[m]\n\t"
+                        "ds_read_b32 %[c], %[c] offset:%[lut]\n\t"
+                        "ds_read_b32 %[t], %[t] offset:%[lut]\n\t"
+                        "ds_read_b32 %[m], %[m] offset:%[lut]\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "v_add_f32 %[m], 0x4b000000, %[m]\n\t"
+                        "v_fmac_f32 %[m], 2.0, %[t]\n\t"
+                        "v_fmac_f32 %[m], 4.0, %[c]\n\t"
+                        "s_mov_b32 %[pos], 15\n\t"
+                        "s_branch 4b\n"
+                        "2:\n\t"
+                        "s_waitcnt vmcnt(0)\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [w] "+v"(w), [nidx] "+v"(nidx), [off] "+v"(off), [c] "+v"(c), [t] "=&v"(tmp), [sp] "+v"(sp), [sh] "+v"(sh), [m] "+v"(m),
+                          [trips] "+s"(trips), [pos] "+s"(pos), [sv] "=&s"(saved)
+                        : [m0] "v"(mu0), [m1] "v"(mu1), [m2] "v"(mu2), [rs] "s"(rs_asm), [row] "s"((uint32_t)(BLOCK * 4)), [lut] "n"(LOFF * 4)
                         : "vcc", "scc", "memory");
                 } else if (!CNT && (int32_t)w >= 0) {
                     uint32_t tmp;
@@ -847,10 +955,21 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
         }
     }
 
+    // timeline build, second region of the debug buffer (16 words per wave behind the first 16384 x 16): slot 0 = the moment the wave
+    // enters its main loop (top table staged, the camera's walk made), slots 1..14 = the moments of its first fourteen ray generations, slot 15 = where it runs
+    // list-share feedback (launch_post): when the frame's first waves started -- the first workgroup of every list stamps --
+    if (fresh_args().balance != nullptr && blockIdx.x < kShards && tid == 0u)
+        __hip_atomic_fetch_min(fresh_args().balance + 9, (uint32_t)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (DBG) {
+        uint32_t *const ev = fresh_args().debug + 16u * 16384u + 16u * wave_id;
+        if (lane == 0u) ev[0] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        // slot 15: where the wave runs -- HW_REG_XCC_ID[3:0] << 16 | HW_REG_HW_ID[15:0] (wave, SIMD, pipe, CU, SH, SE)
+        if (lane == 0u) ev[15] = (((uint32_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20)) << 16) | (uint32_t)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);
+    }
     for (;;) {
-        if (DBG) c_mark = __builtin_amdgcn_s_memtime();
-        if (DBG) {  // per-wave timeline build only (SVO_OPT_DEBUG_BUFFER): the default instantiation carries none of this
-            n_rounds += 1;
+        if (DBGH) c_mark = __builtin_amdgcn_s_memtime();
+        if (DBG) n_rounds += 1;
+        if (DBGH) {  // per-wave timeline build only (SVO_OPT_DEBUG_BUFFER): the default instantiation carries none of this
             const uint32_t nd = (uint32_t)__popcll(__ballot(sabs(stf) == ST_DESC));
             (void)nd;
             if (!CNT) dbg_desc_rounds += nd ? 1u : 0u;
@@ -859,7 +978,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
         if (sabs(stf) == ST_DESC) {
             descend();
         }
-        if (DBG) {
+        if (DBGH) {
             const uint64_t now = __builtin_amdgcn_s_memtime();
             c_desc += (uint32_t)(now - c_mark);
             c_mark = now;
@@ -875,7 +994,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
         const uint32_t n_idle = 64u - (uint32_t)__popcll(act);
         if (n_idle >= a.refill_min) {
             if (next == 0xFFFFFFFEu && pool_n == 0u) {  // now the answer of the early claim is needed
-                const uint64_t c_w0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
+                const uint64_t c_w0 = DBGH ? __builtin_amdgcn_s_memtime() : 0ull;
                 uint32_t lst = home / kSubs;
                 uint32_t s = entry_of(lst, __builtin_amdgcn_readfirstlane(pend) * kSubs + home % kSubs + ((gridDim.x + kShards - 1u - lst) / kShards) * (uint32_t)(BLOCK / 64));
                 // The home counter ran out: lane i looks at counter i -- one load for all 64 -- and the wave draws from the first
@@ -912,15 +1031,19 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                 s = __builtin_amdgcn_readfirstlane(s);
                 next = s != 0xFFFFFFFFu ? s * strip_items : 0xFFFFFFFFu;
                 strip_end = s != 0xFFFFFFFFu ? min(next + strip_items, n_items) : 0xFFFFFFFFu;
-                if (DBG && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
-                if (DBG && !CNT) dbg_desc_start += (uint32_t)(__builtin_amdgcn_s_memtime() - c_w0);  // (slot 15: cycles spent waiting for claims)
+                if (DBG && next == 0xFFFFFFFFu && t_dry == 0) t_dry = (uint32_t)__builtin_amdgcn_s_memrealtime() | 1u;
+                if (DBGH && !CNT) dbg_desc_start += (uint32_t)(__builtin_amdgcn_s_memtime() - c_w0);  // (slot 15: cycles spent waiting for claims)
             }
             const bool more = (pool_n != 0u) || (next != 0xFFFFFFFFu);
             if (more) {
-                if (DBG) dbg_refills += 1;
+                if (DBGH) dbg_refills += 1;
                 if (pool_n == 0u) {
                     if (DBG) dbg_gens += 1;
-                    const uint64_t c_g0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
+                    if (DBG && dbg_gens <= 14u) {
+                        uint32_t *const ev = fresh_args().debug + 16u * 16384u + 16u * wave_id + dbg_gens;
+                        if (lane == 0u) ev[0] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+                    }
+                    const uint64_t c_g0 = DBGH ? __builtin_amdgcn_s_memtime() : 0ull;
                     // -- generate the next (up to) 64 rays, all lanes --
                     const TraceArgs &a = fresh_args();  // (shadows the parameter: see fresh_args)
                     const uint32_t q = next + lane;
@@ -979,10 +1102,17 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                     next += min(64u, strip_end - next);
                     if (next >= strip_end) {
                         if (lane == 0) pend = atomicAdd(work_counter + home * kShardStride, 1u);
+#ifdef SVO_PROBE_CLAIM_LATENCY   // (light timeline build: how long a claim's answer takes under the kernel's own load, slot 15)
+                        if (DBG) {
+                            const uint64_t c_a0 = __builtin_amdgcn_s_memtime();
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            dbg_desc_start += (uint32_t)(__builtin_amdgcn_s_memtime() - c_a0);
+                        }
+#endif
                         next = strip_end = 0xFFFFFFFEu;  // not known yet (and not "dry")
                     }
-                    if (DBG && next == 0xFFFFFFFFu && t_dry == 0) t_dry = __builtin_amdgcn_s_memrealtime();
-                    if (DBG) c_gen += (uint32_t)(__builtin_amdgcn_s_memtime() - c_g0);
+                    if (DBG && next == 0xFFFFFFFFu && t_dry == 0) t_dry = (uint32_t)__builtin_amdgcn_s_memrealtime() | 1u;
+                    if (DBGH) c_gen += (uint32_t)(__builtin_amdgcn_s_memtime() - c_g0);
                 }
                 // -- idle lanes first write the record of the ray they finished, then take rays pool_i .. --
                 if (sabs(stf) == ST_PENDING) flush_record(true);
@@ -1057,7 +1187,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             if (act == 0ull && pool_n == 0u && next == 0xFFFFFFFFu) break;
         }
 
-        if (DBG) {
+        if (DBGH) {
             dbg_active += (uint32_t)__popcll(__ballot(sabs(stf) == ST_LEAF));
             const uint64_t now = __builtin_amdgcn_s_memtime();
             c_refill += (uint32_t)(now - c_mark);
@@ -1076,7 +1206,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             // Final counters = min(15, old + visits), like the RESTART kernel.
             // (Wave-uniform control flow around per-lane predicates: the queue cursor is a scalar.)
             const bool at_leaf = sabs(stf) == ST_LEAF;
-            const uint64_t c_c0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
+            const uint64_t c_c0 = DBGH ? __builtin_amdgcn_s_memtime() : 0ull;
             if (__ballot(at_leaf) != 0ull) {
                 const uint32_t L = min((uint32_t)D - sh_of(sh), (uint32_t)SMAX);  // (a word below level SMAX ends the ray: the tree is deeper than declared)
                 uint32_t todo = at_leaf ? (~satm & ((1u << L) - 2u)) : 0u;  // levels 1 .. L-1 not known to be saturated
@@ -1097,7 +1227,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                     bool mine = todo != 0u;
                     const uint32_t l = mine ? (uint32_t)__builtin_ctz(todo) : 1u;
                     todo &= todo - 1u;
-                    if (DBG && lane == 0u) dbg_desc_iters += 1u;  // (CNT: slot 12 = iterations of this loop)
+                    if (DBGH && lane == 0u) dbg_desc_iters += 1u;  // (CNT: slot 12 = iterations of this loop)
                     const uint32_t kk = l - 1u, shc = (uint32_t)D - kk;
                     uint32_t g = 0u;
                     if (l >= (uint32_t)SBASE) {
@@ -1121,7 +1251,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                     cq_push(mine, p, 0u);
                 }
             }
-            if (DBG) dbg_desc_start += (uint32_t)(__builtin_amdgcn_s_memtime() - c_c0);  // (CNT: slot 15 = cycles spent counting)
+            if (DBGH) dbg_desc_start += (uint32_t)(__builtin_amdgcn_s_memtime() - c_c0);  // (CNT: slot 15 = cycles spent counting)
         }
         // ---- 3. hit test / DDA step (shader.wgsl:215-244), clean rays, grid units; see the header of this kernel ----
         if (sabs(stf) == ST_LEAF) {  // at a leaf (rays picked up above descend first)
@@ -1197,23 +1327,31 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                 }
             }
         }
-        if (DBG) c_step += (uint32_t)(__builtin_amdgcn_s_memtime() - c_mark);
+        if (DBGH) c_step += (uint32_t)(__builtin_amdgcn_s_memtime() - c_mark);
     }
     if (CNT) cq_flush();
-    if (DBG) {  // wave totals of the per-lane tallies
+    if (DBGH) {  // wave totals of the per-lane tallies
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             dbg_desc_iters += (uint32_t)__shfl_xor((int)dbg_desc_iters, o);
             dbg_desc_lanes += (uint32_t)__shfl_xor((int)dbg_desc_lanes, o);
         }
     }
-    if (DBG) {  // the rays that finish last: their step counts tell whether the tail is long rays or late starts
+    if (DBGH) {  // the rays that finish last: their step counts tell whether the tail is long rays or late starts
         uint32_t last = sabs(stf) == ST_PENDING ? (uint32_t)stepsf : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) last = max(last, (uint32_t)__shfl_xor((int)last, o));
         dbg_iters = last;
     }
     if (sabs(stf) == ST_PENDING) flush_record(false);
+    // -- and when the waves that started on list l (the XCD the list belongs to) were done
+    {
+        uint32_t *const bal = fresh_args().balance;
+        // (every 8th workgroup of a list stores its stamp in a slot of its own -- plain stores: an atomic on one address is executed
+        // at the memory side, 11 ns apiece, and 7168 waves adding to 8 words at their exit held the END of the kernel up by 10 us)
+        if (bal != nullptr && tid == 0u && (blockIdx.x / kShards) % kBalanceEvery == 0u && blockIdx.x / (kShards * kBalanceEvery) < kBalanceSlots / kShards)
+            bal[kBalanceHead + blockIdx.x / (kShards * kBalanceEvery) * kShards + blockIdx.x % kShards] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    }
     if (DBG && lane == 0) {
         uint64_t t_end = __builtin_amdgcn_s_memrealtime();
         uint32_t *d = a.debug + 16u * wave_id;
@@ -1225,8 +1363,8 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
         d[13] = dbg_desc_lanes;  // lanes inside the loop, summed over its iterations
         d[14] = dbg_desc_rounds; // rounds in which any lane descended
         d[15] = dbg_desc_start;  // cycles spent waiting for the answers of strip claims (CNT: cycles spent counting)
-        d[0] = (uint32_t)t_begin;
-        d[1] = (uint32_t)(t_dry ? t_dry : t_end);
+        d[0] = t_begin;
+        d[1] = t_dry ? t_dry : (uint32_t)t_end;
         d[2] = (uint32_t)t_end;
         d[3] = n_rounds;
         d[4] = dbg_active;   // sum over rounds of active lanes
@@ -1346,8 +1484,61 @@ __global__ __launch_bounds__(256) void scan_kernel(uint32_t *nodes, uint32_t n_w
 // and re-arm the claim counters.  A strip whose deferred rays are written by another workgroup of this
 // launch may see their old records; that only perturbs the schedule, never a result.
 // ---------------------------------------------------------------------------------------------
+// List shares (round 5).  Every list is one XCD's, and the XCDs do not take the same time over the same number of strips: a list's part of
+// the screen decides how deep its rays walk and how many lines its L2 has to fetch (the middle columns of the benchmark frame: 50 k
+// lines, the outer ones 10 k), and with claims running ahead no list has anything left to steal when the fast XCDs are done -- they
+// end 13 - 15 us before the slow ones (profiles/r05_xcd_imbalance.txt).  So the trace kernel stamps when the waves of every list
+// ended (the mean over a sample of its workgroups: the latest wave is a noisy figure), and the lists' shares of every cost class
+// follow: share *= 1 + gain (mean / time - 1), clamped per step and in total.
+// (called by all 256 threads of one workgroup)
+__device__ __forceinline__ void balance_step(uint32_t *bal, bool update, float gain) {
+    __shared__ float t_sum[8], t_n[8];
+    const uint32_t t0 = bal[9];
+    if (threadIdx.x < 8u) t_sum[threadIdx.x] = t_n[threadIdx.x] = 0.0f;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kBalanceSlots; i += 256u) {  // slot i: a workgroup of list i % 8
+        const uint32_t e = bal[kBalanceHead + i];
+        const float t = (float)(e - t0);  // (10 ns ticks; the difference survives a wrap of the counter)
+        if (update && e != 0u && t > 0.0f && t < 1.0e8f) {
+            atomicAdd(&t_sum[i & 7u], t);
+            atomicAdd(&t_n[i & 7u], 1.0f);
+        }
+        bal[kBalanceHead + i] = 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0u) return;
+    if (update) {
+        float T[8], w[8], mean = 0.0f;
+        bool ok = t0 != 0xFFFFFFFFu;
+        for (int k = 0; k < 8; k++) {
+            ok = ok && t_n[k] > 0.0f;
+            T[k] = ok ? t_sum[k] / t_n[k] : 1.0f;
+            w[k] = (float)(bal[k + 1] - bal[k]);
+            mean += T[k] * 0.125f;
+        }
+        if (ok) {
+            float sum = 0.0f;
+            for (int k = 0; k < 8; k++) {
+                const float r = fminf(fmaxf(mean / T[k], 0.8f), 1.25f);
+                w[k] = fminf(fmaxf(w[k] * (1.0f + gain * (r - 1.0f)), 0.6f * 8192.0f), 1.6f * 8192.0f);
+                sum += w[k];
+            }
+            uint32_t acc = 0u;
+            float run = 0.0f;
+            for (int k = 0; k < 8; k++) {
+                bal[k] = acc;
+                run += w[k];
+                acc = k == 7 ? 65536u : (uint32_t)(run / sum * 65536.0f + 0.5f);
+            }
+            bal[8] = 65536u;
+            bal[18] += 1u;
+        }
+    }
+    bal[9] = 0xFFFFFFFFu;
+}
+
 __global__ __launch_bounds__(256) void post_kernel(TraceArgs a, uint32_t *claim_counters, const uint32_t *list,
-                                                   uint32_t *next_deferred_count, uint8_t *cost, uint32_t n_strips) {
+                                                   uint32_t *next_deferred_count, uint8_t *cost, uint32_t n_strips, uint32_t balance_update) {
     const rsrc_t rs = make_rsrc(a.nodes, a.n_words);
     const bool misc_bool = (a.u.flags & SVO_F_MISC_BOOL) != 0;
     // re-arm for the next frame: the claim counters (the trace kernel is done with them) and the deferred
@@ -1355,6 +1546,8 @@ __global__ __launch_bounds__(256) void post_kernel(TraceArgs a, uint32_t *claim_
     if (blockIdx.x == 0) {
         for (uint32_t i = threadIdx.x; i < (uint32_t)kCounterWords; i += 256u) claim_counters[i] = 0u;
         if (threadIdx.x == 0) *next_deferred_count = 0u;
+        // (balance_update: 0 = only reset the stamps; n > 0 = the n-th frame fed back: the first steps are large, the later ones small)
+        if (a.balance != nullptr) balance_step(a.balance, balance_update != 0u, balance_update <= 6u ? 0.6f : 0.25f);
     }
     const uint32_t n_def = list[0];
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_def; i += gridDim.x * 256u) {
@@ -1408,7 +1601,19 @@ __device__ __forceinline__ uint32_t order_chunk(uint32_t n_strips) {
     return (((n_strips + kOrderBlocks - 1) / kOrderBlocks) + 63u) & ~63u;  // whole 64-strip groups per workgroup
 }
 
-__global__ __launch_bounds__(kOrderThreads) void strip_hist_kernel(const uint8_t *cls, uint32_t n_strips, uint32_t *hist) {
+// Round 5: the strips of a class are ranked COLUMN by column when the frame is one rectangle of pixel blocks (bpr = blocks per row, else
+// 0: strip order): a list's segment of a class is then a vertical slab of the screen, and the slabs of the different classes of one list
+// overlap -- the lists (one per XCD, each with an L2 of its own) share fewer nodes: 225 k instead of 272 k cache lines fetched per
+// frame by the eight L2s together on the benchmark frame (180 k distinct; row-major ranks cut every class into horizontal bands that
+// lie elsewhere for every class), profiles/r05_footprint_by_partition.txt.
+__device__ __forceinline__ uint32_t order_strip_at(uint32_t p, uint32_t n_strips, uint32_t bpr) {
+    if (bpr == 0u) return p;
+    const uint32_t rows = n_strips / bpr;  // (the caller passes bpr only when n_strips is rows * bpr)
+    const uint32_t col = p / rows;
+    return (p - col * rows) * bpr + col;
+}
+
+__global__ __launch_bounds__(kOrderThreads) void strip_hist_kernel(const uint8_t *cls, uint32_t n_strips, uint32_t *hist, uint32_t bpr) {
     __shared__ uint32_t tally[kOrderBins];
     if (threadIdx.x < kOrderBins) tally[threadIdx.x] = 0;
     __syncthreads();
@@ -1417,7 +1622,7 @@ __global__ __launch_bounds__(kOrderThreads) void strip_hist_kernel(const uint8_t
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t base = lo + (threadIdx.x & ~63u); base < hi; base += kOrderThreads) {
         const uint32_t s = base + lane;
-        const uint32_t c = s < hi ? cls[s] : 0xFFu;
+        const uint32_t c = s < hi ? cls[order_strip_at(s, n_strips, bpr)] : 0xFFu;
         uint64_t todo = __ballot(c != 0xFFu);
         while (todo) {  // one LDS atomic per (wave, class present) instead of one per strip
             const uint32_t b = __builtin_amdgcn_readlane(c, __ffsll((unsigned long long)todo) - 1);
@@ -1431,9 +1636,12 @@ __global__ __launch_bounds__(kOrderThreads) void strip_hist_kernel(const uint8_t
 }
 
 __global__ __launch_bounds__(kOrderThreads) void strip_order_kernel(const uint8_t *cls, const uint32_t *hist, uint32_t *sched,
-                                                                    uint32_t n_strips, uint32_t cap) {
+                                                                    uint32_t n_strips, uint32_t cap, uint32_t bpr, const uint32_t *shares) {
     constexpr uint32_t kWaves = kOrderThreads / 64;
-    __shared__ uint32_t class_n[kOrderBins], before[kOrderBins], seglen[kOrderBins], seg_magic[kOrderBins];
+    __shared__ uint32_t class_n[kOrderBins], before[kOrderBins];
+    // bound[c][k]: rank (inside class c) of the first strip that goes to list k -- equal eighths, or the shares of the lists
+    // (`shares`: nine cumulative 16-bit fractions 0 .. 65536, from the times the lists took in an earlier frame: see launch_post)
+    __shared__ uint32_t bound[kOrderBins][kOrderLists + 1];
     __shared__ uint32_t list_base[kOrderBins][kOrderLists];
     __shared__ uint32_t wave_tot[kOrderBins][kWaves];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -1446,20 +1654,19 @@ __global__ __launch_bounds__(kOrderThreads) void strip_order_kernel(const uint8_
         }
         class_n[tid] = total;
         before[tid] = prior;
-        const uint32_t sl = max((total + kOrderLists - 1) / kOrderLists, 1u);
-        seglen[tid] = sl;
-        seg_magic[tid] = sl <= 1u ? 0u : (uint32_t)(0x100000000ull / sl) + 1u;
+        for (uint32_t k = 0; k <= kOrderLists; k++) {
+            const uint32_t frac = shares ? shares[k] : (k << 16) / kOrderLists;
+            bound[tid][k] = k == kOrderLists ? total : (uint32_t)(((uint64_t)total * frac + 32768u) >> 16);
+        }
     }
     __syncthreads();
     if (tid < kOrderLists) {
         uint32_t acc = 0;
         for (int b = kOrderBins - 1; b >= 0; b--) {  // expensive classes first
             list_base[b][tid] = acc;
-            const uint32_t n = class_n[b], sl = seglen[b];
-            const uint32_t begin = min(tid * sl, n), endp = min(begin + sl, n);
-            acc += endp - begin;
+            acc += bound[b][tid + 1] - bound[b][tid];
         }
-        if (blockIdx.x == 0) sched[tid] = acc;
+        if (blockIdx.x == 0) sched[tid] = min(acc, cap);
     }
     // each wave owns a contiguous run of 64-strip groups of the chunk; lanes 0..31 keep the class tallies
     const uint32_t chunk = order_chunk(n_strips);
@@ -1469,7 +1676,7 @@ __global__ __launch_bounds__(kOrderThreads) void strip_order_kernel(const uint8_
     uint32_t tally = 0;
     for (uint32_t base = lo; base < hi; base += 64u) {
         const uint32_t s = base + lane;
-        const uint32_t c = s < hi ? cls[s] : 0xFFu;
+        const uint32_t c = s < hi ? cls[order_strip_at(s, n_strips, bpr)] : 0xFFu;
         uint64_t todo = __ballot(c != 0xFFu);
         while (todo) {
             const uint32_t b = __builtin_amdgcn_readlane(c, __ffsll((unsigned long long)todo) - 1);
@@ -1486,8 +1693,8 @@ __global__ __launch_bounds__(kOrderThreads) void strip_order_kernel(const uint8_
         for (uint32_t w = 0; w < wv; w++) run += wave_tot[lane][w];
     }
     for (uint32_t base = lo; base < hi; base += 64u) {
-        const uint32_t s = base + lane;
-        const uint32_t c = s < hi ? cls[s] : 0xFFu;
+        const uint32_t s = order_strip_at(base + lane, n_strips, bpr);  // (positions past the chunk's end are not looked at)
+        const uint32_t c = base + lane < hi ? cls[s] : 0xFFu;
         uint64_t todo = __ballot(c != 0xFFu);
         uint32_t rank = 0;
         while (todo) {
@@ -1500,9 +1707,11 @@ __global__ __launch_bounds__(kOrderThreads) void strip_order_kernel(const uint8_
             todo &= ~m;
         }
         if (c != 0xFFu) {
-            const uint32_t sl = seglen[c];
-            const uint32_t list = fast_div(rank, sl, seg_magic[c]), within = rank - list * sl;
-            sched[kOrderLists + list * cap + list_base[c][list] + within] = s;
+            uint32_t list = 0;
+#pragma unroll
+            for (uint32_t k = 1; k < kOrderLists; k++) list += rank >= bound[c][k] ? 1u : 0u;
+            const uint32_t at = list_base[c][list] + (rank - bound[c][list]);
+            if (at < cap) sched[kOrderLists + list * cap + at] = s;  // (cap: order_list_cap, which bounds a list's share)
         }
     }
 }
@@ -1677,7 +1886,8 @@ static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipS
                                          : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, false>)
                            : (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false>
                                          : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false>));
-    size_t lds_bytes = (size_t)((SVO_TOP_IN_LDS ? (1 << (3 * kTopLevels)) : 0) + NS * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
+    // (64: the walk's bit-spreading table, kLutWords in the kernel -- every instantiation reserves it; the stacks stay the last region)
+    size_t lds_bytes = (size_t)((SVO_TOP_IN_LDS ? (1 << (3 * kTopLevels)) : 0) + 64 + NS * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
                                 (args.count_nodes ? (kStackBlock / 64) * kCountQueue + kSatTags + (1 << (3 * kTopLevels)) / 8 : 0)) * sizeof(uint32_t);
     // cached per context (= per device): [deep stack?][fused shadows?][counting instantiation?]
     int &blocks_per_cu = li.occupancy[(args.debug ? 8 : 0) + (NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
@@ -1833,6 +2043,24 @@ __global__ __launch_bounds__(256) void strip_cull_kernel(TraceArgs a, const uint
     }
 }
 
+// blocks per row for the schedule builder's column-major ranks (0: rank in strip order): frames of one rectangle of whole pixel blocks
+#ifndef SVO_ORDER_COLMAJOR
+#define SVO_ORDER_COLMAJOR 1
+#endif
+static uint32_t order_bpr(const WorkDesc &w, uint32_t n_strips) {
+    if (!SVO_ORDER_COLMAJOR || w.mode == 2 || w.n_rects > 1u || w.bpr == 0u || n_strips % w.bpr != 0u || n_strips * 64u != w.n_items) return 0u;
+    return w.bpr;
+}
+
+// the two kernels of the schedule builder for the class bytes `cls` (the chunk histograms live behind them)
+static void launch_order_pair(const WorkDesc &w, const uint8_t *cls, uint32_t *sched, uint32_t n_strips, uint32_t cap, hipStream_t stream,
+                              const uint32_t *shares = nullptr) {
+    uint32_t *hist = reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(cls) + ((n_strips + 15u) & ~15u));
+    const uint32_t bpr = order_bpr(w, n_strips);
+    hipLaunchKernelGGL(strip_hist_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, cls, n_strips, hist, bpr);
+    hipLaunchKernelGGL(strip_order_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, cls, (const uint32_t *)hist, sched, n_strips, cap, bpr, shares);
+}
+
 // This frame's strip lists without the culled strips (classes from `prev`, or screen order); see launch_schedule_skipping.
 hipError_t launch_schedule_culling(const TraceArgs &args, const uint8_t *prev, uint8_t *cls, uint32_t *sched, uint32_t n_strips,
                                    uint32_t cap, hipStream_t stream) {
@@ -1840,10 +2068,7 @@ hipError_t launch_schedule_culling(const TraceArgs &args, const uint8_t *prev, u
     uint32_t blocks = (n_strips + 255u) / 256u;  // a lane per strip
     if (blocks > 8192u) blocks = 8192u;
     hipLaunchKernelGGL(strip_cull_kernel, dim3(blocks), dim3(256), 0, stream, args, prev, cls, n_strips);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(cls + ((n_strips + 15u) & ~15u));
-    hipLaunchKernelGGL(strip_hist_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, (const uint8_t *)cls, n_strips, hist);
-    hipLaunchKernelGGL(strip_order_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, (const uint8_t *)cls,
-                       (const uint32_t *)hist, sched, n_strips, cap);
+    launch_order_pair(args.work, cls, sched, n_strips, cap, stream);
     return hipGetLastError();
 }
 
@@ -1852,9 +2077,9 @@ hipError_t launch_schedule_skipping(const uint8_t *skip, uint32_t n_items, const
     (void)hipGetLastError();
     hipLaunchKernelGGL(strip_classes_kernel, dim3((n_strips + 255u) / 256u), dim3(256), 0, stream, skip, n_items, prev, cls, n_strips);
     uint32_t *hist = reinterpret_cast<uint32_t *>(cls + ((n_strips + 15u) & ~15u));  // same layout as the cost buffer
-    hipLaunchKernelGGL(strip_hist_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, (const uint8_t *)cls, n_strips, hist);
+    hipLaunchKernelGGL(strip_hist_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, (const uint8_t *)cls, n_strips, hist, 0u);
     hipLaunchKernelGGL(strip_order_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, (const uint8_t *)cls,
-                       (const uint32_t *)hist, sched, n_strips, cap);
+                       (const uint32_t *)hist, sched, n_strips, cap, 0u, (const uint32_t *)nullptr);  // (explicit rays: strip order)
     return hipGetLastError();
 }
 
@@ -1887,14 +2112,14 @@ __global__ __launch_bounds__(256) void strip_danger_kernel(const uint8_t *in, ui
 }
 
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
-                       uint32_t cap, bool build_schedule, hipStream_t stream, uint8_t *moved, uint32_t motion_floor) {
+                       uint32_t cap, bool build_schedule, hipStream_t stream, uint8_t *moved, uint32_t motion_floor, uint32_t balance_update) {
     // without the cost pass the launch only re-arms counters and traces deferred rays: normally none, but a frame
     // full of them (every ray NaN / extreme) must not crawl through 16 workgroups
     uint32_t blocks = cost ? (n_strips + 3u) / 4u : 256u;
     if (blocks > 2048u) blocks = 2048u;
     if (blocks < 16u) blocks = 16u;
     hipLaunchKernelGGL(post_kernel, dim3(blocks), dim3(256), 0, stream, args, li.counters, (const uint32_t *)li.defer,
-                       li.next_defer_count, cost, n_strips);
+                       li.next_defer_count, cost, n_strips, balance_update);
     if (cost && build_schedule) {
         const uint8_t *cls = cost;
         if (moved && motion_floor) {  // (pixel frames of one rectangle: the ABI passes `moved` only then)
@@ -1902,11 +2127,8 @@ hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cos
                                args.work.bpr, (int)((motion_floor >> 8) & 15u), (motion_floor >> 12) & 255u, ((motion_floor & 15u) << 3) >> kCostShift);  // (the option counts the floor in units of 8 steps)
             cls = moved;
         }
-        // the chunk histograms live behind the class bytes (the ABI allocates kOrderHistWords extra words)
-        uint32_t *hist = reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(cls) + ((n_strips + 15u) & ~15u));
-        hipLaunchKernelGGL(strip_hist_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, cls, n_strips, hist);
-        hipLaunchKernelGGL(strip_order_kernel, dim3(kOrderBlocks), dim3(kOrderThreads), 0, stream, cls,
-                           (const uint32_t *)hist, sched, n_strips, cap);
+        // (the chunk histograms live behind the class bytes: the ABI allocates kOrderHistWords extra words)
+        launch_order_pair(args.work, cls, sched, n_strips, cap, stream, args.balance);
     }
     return hipGetLastError();
 }

@@ -4,11 +4,12 @@
 #   ROUNDS=4 REPS=150 tools/ab2.sh build/a.so build/b.so ...      (AB_ARGS: extra perf_probe.py arguments)
 ROUNDS=${ROUNDS:-4}; REPS=${REPS:-150}
 for rep in $(seq $ROUNDS); do
-for lib in "$@"; do
-  SVO_HIP_LIB=$PWD/$lib python tools/perf_probe.py --lod 1500 --variants 1 --refill 16 --schedule 2 --reps $REPS ${AB_ARGS:-} 2>/dev/null | grep '^{' | python3 -c "
+for entry in "$@"; do
+  lib=${entry%%:*}; envs=""; [ "$entry" != "$lib" ] && envs=${entry#*:}   # build.so or build.so:VAR=value (an environment switch of the library)
+  env $envs SVO_HIP_LIB=$PWD/$lib python tools/perf_probe.py --lod 1500 --variants 1 --refill 16 --schedule 2 --reps $REPS ${AB_ARGS:-} 2>/dev/null | grep '^{' | python3 -c "
 import sys,json
 for l in sys.stdin:
-    d=json.loads(l); print('$lib', d['ms_med'], d['ms_min'], d['sig'])"
+    d=json.loads(l); print('$entry', d['ms_med'], d['ms_min'], d['sig'])"
 done; done | tee /tmp/ab2_raw.txt | python3 -c "
 import sys,collections
 r=collections.defaultdict(list); sig={}

@@ -14,12 +14,25 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as entry  # noqa: E402
 
 
+def progress(ev, d, t0):
+    gens = ev[:, 1:15]
+    gens = (gens[gens != 0] - t0) * 0.01
+    enter, dry, end = (ev[:, 0] - t0) * 0.01, (d[:, 1] - t0) * 0.01, (d[:, 2] - t0) * 0.01
+    rows = []
+    for b in range(int(end.max() // 10) + 1):
+        lo, hi = b * 10.0, b * 10.0 + 10.0
+        rows.append({"t_us": lo, "strips_generated": int(((gens >= lo) & (gens < hi)).sum()), "waves_in_loop": int(((enter < hi) & (end >= lo)).sum()),
+                     "waves_not_dry": int(((enter < hi) & (dry >= lo)).sum())})
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scene", default="terrain")
     ap.add_argument("--w", type=int, default=1920)
     ap.add_argument("--h", type=int, default=1080)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--raw", default=None, help="save the per-wave words (timeline, events) as .npz")
     ap.add_argument("--count", action="store_true", help="hit counters live, cleared before the frame (the reference's default mode)")
     ap.add_argument("--carry", action="store_true", help="with --count: the counters carry over from frame to frame (no scan in between)")
     ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE for gpu.set_option (e.g. REFILL_MIN=8)")
@@ -53,10 +66,10 @@ def main():
     for o in a.opt:
         k, v = o.split("=")
         gpu.set_option(getattr(pkg.gpu, "OPT_" + k), int(v))
-    dbg = torch.zeros((16384, 16), dtype=torch.int32, device="cuda")
+    dbg = torch.zeros((2 * 16384, 16), dtype=torch.int32, device="cuda")  # second half: per-wave event stamps (round 5)
     hits = render.alloc_hits(W * H)
     gpu.set_option(pkg.gpu.OPT_TIMING, 8)
-    for _ in range(8 if a.carry else 4):
+    for _ in range(8 if a.carry else 24):
         clear()
         render.render(hits=hits)
     ms_plain = gpu.last_render_ms()
@@ -70,9 +83,13 @@ def main():
     h = pkg.render.hits_to_numpy(hits)
     steps_mean = float((h["info"] & 0xFF).mean())
     hit_frac = float(((h["info"] >> 16) & 1).mean())
-    d = dbg.cpu().numpy().view(np.uint32)
-    d = d[d[:, 2] != 0].astype(np.int64)
+    d_all = dbg.cpu().numpy().view(np.uint32)
+    live = d_all[:16384, 2] != 0
+    ev = d_all[16384:][live].astype(np.int64)
+    d = d_all[:16384][live].astype(np.int64)
     t0 = d[:, 0].min()
+    if a.raw:
+        np.savez_compressed(a.raw, d=d, ev=ev, wave=np.nonzero(live)[0])
     start, dry, end = (d[:, 0] - t0) * 0.01, (d[:, 1] - t0) * 0.01, (d[:, 2] - t0) * 0.01  # us
     pct = [0, 1, 5, 25, 50, 75, 95, 99, 100]
     rounds = d[:, 3].sum()
@@ -102,6 +119,11 @@ def main():
                     "wave_iters_per_descending_round": round(float(d[:, 12].sum() / max(d[:, 14].sum(), 1)), 2),
                     "lanes_in_loop_per_iter": round(float(d[:, 13].sum() / max(d[:, 12].sum(), 1)), 2),
                     "cycles_per_wave_iter": round(float(d[:, 9].sum() / max(d[:, 12].sum(), 1)), 1)},
+        # round 5: the frame's progress curve.  Per 10 us bin: strips generated (first 15 generations of every wave), waves that have
+        # entered their main loop and not ended, waves that do not know yet that the lists are empty
+        "loop_entry_us": np.percentile((ev[:, 0] - t0) * 0.01, pct).round(1).tolist(),
+        "camera_walk_us": np.percentile((ev[:, 0] - d[:, 0]) * 0.01, pct).round(2).tolist(),
+        "progress_10us": progress(ev, d, t0),
         "last_ray_steps_by_end_decile": [int(np.median(d[np.argsort(end)][i * len(d) // 10:(i + 1) * len(d) // 10, 5])) for i in range(10)],
     }
     print(json.dumps(out, indent=1))
