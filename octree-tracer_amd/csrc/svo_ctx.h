@@ -59,7 +59,7 @@ struct svo_ctx {
     int variant = SVO_VARIANT_STACK;
     int grid_blocks = 0;
     int occupancy[16] = {};  // resident workgroups per CU of each STACK instantiation on this device (0: not asked yet)
-    uint32_t refill_min = 16;
+    uint32_t refill_min = 32;  // (round 5: 16 until the schedule's locality work; profiles/r05_refill_sweep.log)
     bool scan_clears = false;
     int fused_shadows = 2;  // 0: off, 1: on, 2: by frame size and tree depth (see trace_common)
     void *scatter_buf = nullptr;

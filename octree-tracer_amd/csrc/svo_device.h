@@ -83,7 +83,10 @@ constexpr uint32_t kMaxScheduledStrips = 1u << 20;  // (2^26 items / 64)
 // cost class of a strip = (largest step count among its rays) >> kCostShift: 4 steps per class -- with 8 the cheapest two classes of the
 // benchmark view hold 3 439 of 32 400 strips, fewer than the grid has waves, so every wave's last strip came from the 16..23-step
 // class in screen order; the finer classes end the lists with the strips that really are the shortest
-constexpr uint32_t kCostShift = 2, kCostClasses = 32;
+#ifndef SVO_COST_SHIFT
+#define SVO_COST_SHIFT 2
+#endif
+constexpr uint32_t kCostShift = SVO_COST_SHIFT, kCostClasses = 128u >> SVO_COST_SHIFT;
 constexpr uint32_t kOrderHistWords = 64 * kCostClasses;  // chunk histograms of the schedule builder, stored behind the class bytes
 // list-share feedback of a schedule: [0..8] cumulative shares of the 8 lists (16-bit fractions, [0] = 0, [8] = 65536), [9]
 // the last scheduled frame's start stamp, [18] updates so far; behind them (kBalanceHead) kBalanceSlots end stamps: slot i * 8 + l =

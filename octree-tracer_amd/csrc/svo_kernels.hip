@@ -1583,7 +1583,10 @@ __global__ __launch_bounds__(256) void post_kernel(TraceArgs a, uint32_t *claim_
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, o));
-            if (lane == 0) cost[s] = (uint8_t)min(steps >> kCostShift, kCostClasses - 1u);  // cost class
+            if (lane == 0) {
+                uint32_t c = min(steps >> kCostShift, kCostClasses - 1u);  // cost class
+                cost[s] = (uint8_t)c;
+            }
         }
     }
 }

@@ -6,6 +6,10 @@
 
 #include "svo_device.h"
 
+#ifndef SVO_STREAM_RECORDS
+#define SVO_STREAM_RECORDS 1
+#endif
+
 namespace svo {
 
 // ---------------------------------------------------------------------------------------------
@@ -105,12 +109,15 @@ __device__ __forceinline__ bool ray_enter(const RayIn &r, float pos[3], float di
 
 __device__ __forceinline__ void write_hit(svo_hit *hits, uint32_t out, uint32_t value, float t, uint32_t steps,
                                           uint32_t depth, uint32_t hit, uint32_t ncode) {
-    uint4 rec;
-    rec.x = value;
-    rec.y = __float_as_uint(t);
-    rec.z = (steps & 0xFFu) | ((depth & 0xFFu) << 8) | (hit << 16) | (ncode << 17);
-    rec.w = ncode;
-    reinterpret_cast<uint4 *>(hits)[out] = rec;
+    // (round 5: a streaming store -- 33 MB of records per 1080p frame pass through the eight 4 MB L2s, as much as they hold, and the
+    // node lines they push out are fetched again; nobody reads a record before the frame is over)
+    typedef uint32_t rec_t __attribute__((ext_vector_type(4)));
+    const rec_t rec = {value, __float_as_uint(t), (steps & 0xFFu) | ((depth & 0xFFu) << 8) | (hit << 16) | (ncode << 17), ncode};
+#if SVO_STREAM_RECORDS
+    __builtin_nontemporal_store(rec, reinterpret_cast<rec_t *>(hits) + out);
+#else
+    reinterpret_cast<rec_t *>(hits)[out] = rec;
+#endif
 }
 
 __device__ __forceinline__ float code_to_normal(uint32_t c) { return c == 1u ? 1.0f : (c == 2u ? -1.0f : 0.0f); }

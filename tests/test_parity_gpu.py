@@ -1060,7 +1060,7 @@ def test_launch_options_do_not_change_results(pkg, gpu, O, monu9_words):
     period, block shape) only changes HOW the rays are traced: the records stay bit-identical to the oracle's."""
     terrain = pkg.scenes.terrain(seed=2, max_depth=12, cam=(0.1, 0.3, -0.2), lod_c=300.0, max_words=3_000_000)
     G = pkg.gpu
-    defaults = {G.OPT_REFILL_MIN: 16, G.OPT_STRIP_ITEMS: 64, G.OPT_DYNAMIC_STRIPS: 1, G.OPT_GRID_BLOCKS: 0, G.OPT_SCHEDULE: 2,
+    defaults = {G.OPT_REFILL_MIN: 32, G.OPT_STRIP_ITEMS: 64, G.OPT_DYNAMIC_STRIPS: 1, G.OPT_GRID_BLOCKS: 0, G.OPT_SCHEDULE: 2,
                 G.OPT_BLOCK_SHAPE: 3}
     combos = [{G.OPT_REFILL_MIN: 1}, {G.OPT_REFILL_MIN: 64}, {G.OPT_STRIP_ITEMS: 256, G.OPT_SCHEDULE: 0},
               {G.OPT_DYNAMIC_STRIPS: 0, G.OPT_SCHEDULE: 0}, {G.OPT_GRID_BLOCKS: 7}, {G.OPT_GRID_BLOCKS: 4000},

@@ -6,7 +6,7 @@ ROUNDS=${ROUNDS:-4}; REPS=${REPS:-150}
 for rep in $(seq $ROUNDS); do
 for entry in "$@"; do
   lib=${entry%%:*}; envs=""; [ "$entry" != "$lib" ] && envs=${entry#*:}   # build.so or build.so:VAR=value (an environment switch of the library)
-  env $envs SVO_HIP_LIB=$PWD/$lib python tools/perf_probe.py --lod 1500 --variants 1 --refill 16 --schedule 2 --reps $REPS ${AB_ARGS:-} 2>/dev/null | grep '^{' | python3 -c "
+  env $envs SVO_HIP_LIB=$PWD/$lib python tools/perf_probe.py --lod 1500 --variants 1 --refill ${REFILL:-32} --schedule 2 --reps $REPS ${AB_ARGS:-} 2>/dev/null | grep '^{' | python3 -c "
 import sys,json
 for l in sys.stdin:
     d=json.loads(l); print('$entry', d['ms_med'], d['ms_min'], d['sig'])"

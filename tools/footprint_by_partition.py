@@ -103,3 +103,10 @@ def classmix(L,name):
     print(name,"class>=15 per list",[int((cls[l]>=15).sum()) for l in L],"class 8..14",[int(((cls[l]>=8)&(cls[l]<15)).sum()) for l in L])
 for b in ([8],[6,10,15],[4,6,8,12,15]):
     L=lists_groupcol(b); footprint(L,f"group-col {b}"); classmix(L,"   ")
+# coarser classes for the short strips (one sweep of a slab instead of four)
+cls_orig = cls.copy()
+for name, f in (("classes 4..7 merged", lambda c: np.where((c >= 4) & (c < 8), 4, c)), ("classes 2..7 merged", lambda c: np.where((c >= 2) & (c < 8), 2, c)),
+                ("classes 4..7 and 8..11 merged", lambda c: np.where((c >= 4) & (c < 8), 4, np.where((c >= 8) & (c < 12), 8, c)))):
+    cls = f(cls_orig)
+    footprint(lists_colmajor(1), "column-major, " + name)
+cls = cls_orig

@@ -76,9 +76,11 @@ def main():
     gpu.sync()
     clear()
     gpu.set_option(pkg.gpu.OPT_DEBUG_BUFFER, dbg.data_ptr())
-    render.render(hits=hits)
-    ms = gpu.last_render_ms()
-    gpu.sync()
+    for _ in range(2):  # (the first launch of the timeline instantiation starts seven of the eight XCDs 100 us late: its scratch memory is set up then)
+        dbg.zero_()
+        render.render(hits=hits)
+        ms = gpu.last_render_ms()
+        gpu.sync()
     gpu.set_option(pkg.gpu.OPT_DEBUG_BUFFER, 0)
     h = pkg.render.hits_to_numpy(hits)
     steps_mean = float((h["info"] & 0xFF).mean())
