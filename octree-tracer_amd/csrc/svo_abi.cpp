@@ -197,7 +197,6 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         if (!sc.valid) {  // a new layout starts from equal shares of the lists
             uint32_t init[svo::kBalanceWords] = {};
             for (uint32_t k = 0; k <= 8; k++) init[k] = k * 8192u;
-            init[9] = 0xFFFFFFFFu;
             HIP_TRY(ctx, hipMemcpyAsync(sc.balance, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
             sc.balance_frames = 0;
         }

@@ -88,10 +88,10 @@ constexpr uint32_t kMaxScheduledStrips = 1u << 20;  // (2^26 items / 64)
 #endif
 constexpr uint32_t kCostShift = SVO_COST_SHIFT, kCostClasses = 128u >> SVO_COST_SHIFT;
 constexpr uint32_t kOrderHistWords = 64 * kCostClasses;  // chunk histograms of the schedule builder, stored behind the class bytes
-// list-share feedback of a schedule: [0..8] cumulative shares of the 8 lists (16-bit fractions, [0] = 0, [8] = 65536), [9]
-// the last scheduled frame's start stamp, [18] updates so far; behind them (kBalanceHead) kBalanceSlots end stamps: slot i * 8 + l =
-// the i-th sampled workgroup of list l (every kBalanceEvery-th of the list's workgroups stores one; room for 4096 workgroups)
-constexpr uint32_t kBalanceHead = 32, kBalanceEvery = 1, kBalanceSlots = 8 * 512, kBalanceWords = kBalanceHead + kBalanceSlots;
+// list-share feedback of a schedule: [0..8] cumulative shares of the 8 lists (16-bit fractions, [0] = 0, [8] = 65536), [9] the start
+// stamp of the last frame's first workgroup, [18] updates so far, [19] the last trace launch's workgroups; behind them (kBalanceHead) one end stamp per workgroup of the trace
+// launch (workgroup b started on list b % 8)
+constexpr uint32_t kBalanceHead = 32, kBalanceSlots = 4096, kBalanceWords = kBalanceHead + kBalanceSlots;
 // entries reserved per list of a schedule: a list holds its share of every cost class -- an eighth, or what the feedback gives it
 // (at most twice that)
 inline uint32_t order_list_cap(const WorkDesc &, uint32_t n_strips) { return (n_strips + 3u) / 4u + kCostClasses; }

@@ -957,9 +957,13 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
 
     // timeline build, second region of the debug buffer (16 words per wave behind the first 16384 x 16): slot 0 = the moment the wave
     // enters its main loop (top table staged, the camera's walk made), slots 1..14 = the moments of its first fourteen ray generations, slot 15 = where it runs
-    // list-share feedback (launch_post): when the frame's first waves started -- the first workgroup of every list stamps --
-    if (fresh_args().balance != nullptr && blockIdx.x < kShards && tid == 0u)
-        __hip_atomic_fetch_min(fresh_args().balance + 9, (uint32_t)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // list-share feedback (launch_post): when the frame started -- the first workgroup's stamp (plain stores, here and at the end) --
+    {
+        uint32_t *const bal = fresh_args().balance;
+        if (bal != nullptr && blockIdx.x == 0u && tid == 0u) {
+            bal[9] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        }
+    }
     if (DBG) {
         uint32_t *const ev = fresh_args().debug + 16u * 16384u + 16u * wave_id;
         if (lane == 0u) ev[0] = (uint32_t)__builtin_amdgcn_s_memrealtime();
@@ -1347,10 +1351,10 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     // -- and when the waves that started on list l (the XCD the list belongs to) were done
     {
         uint32_t *const bal = fresh_args().balance;
-        // (every 8th workgroup of a list stores its stamp in a slot of its own -- plain stores: an atomic on one address is executed
-        // at the memory side, 11 ns apiece, and 7168 waves adding to 8 words at their exit held the END of the kernel up by 10 us)
-        if (bal != nullptr && tid == 0u && (blockIdx.x / kShards) % kBalanceEvery == 0u && blockIdx.x / (kShards * kBalanceEvery) < kBalanceSlots / kShards)
-            bal[kBalanceHead + blockIdx.x / (kShards * kBalanceEvery) * kShards + blockIdx.x % kShards] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        // (every workgroup stores its stamp in a slot of its own -- plain stores: an atomic on one address is executed at the memory
+        // side, 11 ns apiece, and 7168 waves adding to 8 words at their exit held the END of the kernel up by 10 us)
+        if (bal != nullptr && tid == 0u && blockIdx.x < kBalanceSlots) bal[kBalanceHead + blockIdx.x] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        if (bal != nullptr && tid == 0u && blockIdx.x == 0u) bal[19] = gridDim.x;  // (how many stamps this launch leaves)
     }
     if (DBG && lane == 0) {
         uint64_t t_end = __builtin_amdgcn_s_memrealtime();
@@ -1490,51 +1494,46 @@ __global__ __launch_bounds__(256) void scan_kernel(uint32_t *nodes, uint32_t n_w
 // end 13 - 15 us before the slow ones (profiles/r05_xcd_imbalance.txt).  So the trace kernel stamps when the waves of every list
 // ended (the mean over a sample of its workgroups: the latest wave is a noisy figure), and the lists' shares of every cost class
 // follow: share *= 1 + gain (mean / time - 1), clamped per step and in total.
-// (called by all 256 threads of one workgroup)
-__device__ __forceinline__ void balance_step(uint32_t *bal, bool update, float gain) {
+// (called by all 256 threads of one workgroup, only for frames that are fed back: every workgroup of a frame overwrites its stamp, so
+// nothing has to be cleared in between)
+__device__ __forceinline__ void balance_step(uint32_t *bal, float gain, uint32_t n_slots) {
     __shared__ float t_sum[8], t_n[8];
     const uint32_t t0 = bal[9];
     if (threadIdx.x < 8u) t_sum[threadIdx.x] = t_n[threadIdx.x] = 0.0f;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kBalanceSlots; i += 256u) {  // slot i: a workgroup of list i % 8
-        const uint32_t e = bal[kBalanceHead + i];
-        const float t = (float)(e - t0);  // (10 ns ticks; the difference survives a wrap of the counter)
-        if (update && e != 0u && t > 0.0f && t < 1.0e8f) {
+    for (uint32_t i = threadIdx.x; i < n_slots; i += 256u) {  // slot i: workgroup i, of list i % 8
+        const float t = (float)(bal[kBalanceHead + i] - t0);  // (10 ns ticks; the difference survives a wrap of the counter)
+        if (t > 0.0f && t < 1.0e8f) {
             atomicAdd(&t_sum[i & 7u], t);
             atomicAdd(&t_n[i & 7u], 1.0f);
         }
-        bal[kBalanceHead + i] = 0u;
     }
     __syncthreads();
     if (threadIdx.x != 0u) return;
-    if (update) {
-        float T[8], w[8], mean = 0.0f;
-        bool ok = t0 != 0xFFFFFFFFu;
-        for (int k = 0; k < 8; k++) {
-            ok = ok && t_n[k] > 0.0f;
-            T[k] = ok ? t_sum[k] / t_n[k] : 1.0f;
-            w[k] = (float)(bal[k + 1] - bal[k]);
-            mean += T[k] * 0.125f;
-        }
-        if (ok) {
-            float sum = 0.0f;
-            for (int k = 0; k < 8; k++) {
-                const float r = fminf(fmaxf(mean / T[k], 0.8f), 1.25f);
-                w[k] = fminf(fmaxf(w[k] * (1.0f + gain * (r - 1.0f)), 0.6f * 8192.0f), 1.6f * 8192.0f);
-                sum += w[k];
-            }
-            uint32_t acc = 0u;
-            float run = 0.0f;
-            for (int k = 0; k < 8; k++) {
-                bal[k] = acc;
-                run += w[k];
-                acc = k == 7 ? 65536u : (uint32_t)(run / sum * 65536.0f + 0.5f);
-            }
-            bal[8] = 65536u;
-            bal[18] += 1u;
-        }
+    float T[8], w[8], mean = 0.0f;
+    bool ok = true;
+    for (int k = 0; k < 8; k++) {
+        ok = ok && t_n[k] > 0.0f;
+        T[k] = ok ? t_sum[k] / t_n[k] : 1.0f;
+        w[k] = (float)(bal[k + 1] - bal[k]);
+        mean += T[k] * 0.125f;
     }
-    bal[9] = 0xFFFFFFFFu;
+    if (!ok) return;
+    float sum = 0.0f;
+    for (int k = 0; k < 8; k++) {
+        const float r = fminf(fmaxf(mean / T[k], 0.8f), 1.25f);
+        w[k] = fminf(fmaxf(w[k] * (1.0f + gain * (r - 1.0f)), 0.6f * 8192.0f), 1.6f * 8192.0f);
+        sum += w[k];
+    }
+    uint32_t acc = 0u;
+    float run = 0.0f;
+    for (int k = 0; k < 8; k++) {
+        bal[k] = acc;
+        run += w[k];
+        acc = k == 7 ? 65536u : (uint32_t)(run / sum * 65536.0f + 0.5f);
+    }
+    bal[8] = 65536u;
+    bal[18] += 1u;
 }
 
 __global__ __launch_bounds__(256) void post_kernel(TraceArgs a, uint32_t *claim_counters, const uint32_t *list,
@@ -1546,8 +1545,8 @@ __global__ __launch_bounds__(256) void post_kernel(TraceArgs a, uint32_t *claim_
     if (blockIdx.x == 0) {
         for (uint32_t i = threadIdx.x; i < (uint32_t)kCounterWords; i += 256u) claim_counters[i] = 0u;
         if (threadIdx.x == 0) *next_deferred_count = 0u;
-        // (balance_update: 0 = only reset the stamps; n > 0 = the n-th frame fed back: the first steps are large, the later ones small)
-        if (a.balance != nullptr) balance_step(a.balance, balance_update != 0u, balance_update <= 6u ? 0.6f : 0.25f);
+        // (balance_update: n > 0 = the n-th frame fed back: the first steps are large, the later ones small)
+        if (a.balance != nullptr && balance_update != 0u) balance_step(a.balance, balance_update <= 6u ? 0.6f : 0.25f, min(a.balance[19], kBalanceSlots));
     }
     const uint32_t n_def = list[0];
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_def; i += gridDim.x * 256u) {
