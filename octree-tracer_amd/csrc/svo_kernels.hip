@@ -998,7 +998,11 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
         const uint32_t n_idle = 64u - (uint32_t)__popcll(act);
         if (n_idle >= a.refill_min) {
             if (next == 0xFFFFFFFEu && pool_n == 0u) {  // now the answer of the early claim is needed
-                const uint64_t c_w0 = DBGH ? __builtin_amdgcn_s_memtime() : 0ull;
+                const uint64_t c_w0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
+                if (DBG && !DBGH) {  // (light timeline build, slot 14: cycles until the claim's answer itself is there; slot 15 adds the list look-ups)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    dbg_desc_rounds += (uint32_t)(__builtin_amdgcn_s_memtime() - c_w0);
+                }
                 uint32_t lst = home / kSubs;
                 uint32_t s = entry_of(lst, __builtin_amdgcn_readfirstlane(pend) * kSubs + home % kSubs + ((gridDim.x + kShards - 1u - lst) / kShards) * (uint32_t)(BLOCK / 64));
                 // The home counter ran out: lane i looks at counter i -- one load for all 64 -- and the wave draws from the first
@@ -1036,7 +1040,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                 next = s != 0xFFFFFFFFu ? s * strip_items : 0xFFFFFFFFu;
                 strip_end = s != 0xFFFFFFFFu ? min(next + strip_items, n_items) : 0xFFFFFFFFu;
                 if (DBG && next == 0xFFFFFFFFu && t_dry == 0) t_dry = (uint32_t)__builtin_amdgcn_s_memrealtime() | 1u;
-                if (DBGH && !CNT) dbg_desc_start += (uint32_t)(__builtin_amdgcn_s_memtime() - c_w0);  // (slot 15: cycles spent waiting for claims)
+                if (DBG && !CNT) dbg_desc_start += (uint32_t)(__builtin_amdgcn_s_memtime() - c_w0);  // (slot 15: cycles spent waiting for claims)
             }
             const bool more = (pool_n != 0u) || (next != 0xFFFFFFFFu);
             if (more) {
