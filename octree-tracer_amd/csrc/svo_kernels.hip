@@ -299,6 +299,24 @@ __device__ __forceinline__ const TraceArgs &fresh_args() {
     return *(const TraceArgs *)p;
 }
 
+// LDS of a trace workgroup, in words: ONE definition for the kernel and for the launch's lds_bytes (VERDICT r4 / ADVICE r4: the two
+// must not drift apart).  The ancestor stacks are the LAST region and nothing may be added behind them: the walk does not check the
+// level it has reached, so in a tree deeper than the caller declared a lane pushes rows that do not exist -- beyond the workgroup's
+// allocation, where gfx950 drops the write and reads return 0 (tools/experiments/lds_oob_probe.hip, tests/test_lds_oob_gpu.py) --
+// instead of into another region's data.  A new region goes IN FRONT of `stacks`.
+template <int BLOCK, int NS, int K, bool CNT>
+struct StackLds {
+    static constexpr int top = SVO_TOP_IN_LDS != 0 ? (1 << (3 * K)) : 0;                              // top table
+    static constexpr int lut = top;                                                                   // the walk's bit-spreading table, 64 words
+    static constexpr int pools = lut + 64;                                                            // [BLOCK / 64][kPoolWords][64]
+    static constexpr int counting = pools + (BLOCK / 64) * (kPoolWords * 64);                         // CNT: queues, saturation tags, per-cell flags
+    static constexpr int stacks = counting + (CNT ? (BLOCK / 64) * kCountQueue + kSatTags + (1 << (3 * K)) / 8 : 0);  // [NS][BLOCK], last
+    static constexpr int total = stacks + NS * BLOCK;
+};
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "svo_kernels.hip is written for gfx950: the walk relies on its handling of LDS accesses beyond the allocation and on v_rcp_f32 + one Newton step being the IEEE reciprocal (tools/rcptest_gpu.hip)"
+#endif
+
 // CNT: hit counters live (adaptive mode, shader.wgsl:157-161), see step 3a in the loop.
 template <int BLOCK, int NS, int K, bool GE, bool DBG, bool CNT, bool SHD>
 __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT : ((SHD || (DBG && SVO_DBG_LIGHT == 0)) ? 6 : SVO_WAVES_PER_SIMD))) void trace_stack_kernel(TraceArgs a, uint32_t strip_items,
@@ -310,15 +328,13 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     static_assert(SMAX <= D - 1, "stack deeper than the path codes");
     constexpr int TBL = 1 << (3 * K);
     constexpr bool kTopInLds = SVO_TOP_IN_LDS != 0;
-    // the walk's bit-spreading table (64 words, see descend()): behind the top table, in every instantiation (the host's lds_bytes counts it)
+    using Lds = StackLds<BLOCK, NS, K, CNT>;  // (the layout: one definition for kernel and launch)
     constexpr int kLutWords = 64;
-    constexpr int LOFF = kTopInLds ? TBL : 0;
-    constexpr int TOFF = LOFF + kLutWords;  // LDS words in front of the ray pools
+    constexpr int LOFF = Lds::lut;
+    constexpr int TOFF = Lds::pools;  // LDS words in front of the ray pools
     constexpr bool kLut = SVO_WALK_LUT != 0 && NS <= 12 && !CNT;
-    // The ancestor stacks come LAST in the workgroup's LDS: the walk below does not check the level it has reached (two instructions
-    // per word), so in a tree deeper than the caller declared a lane pushes rows that do not exist -- beyond the allocation, where
-    // the hardware drops the write (and reads return 0: tools/experiments/lds_oob_probe.hip) instead of into another ray's data.
-    constexpr int SOFF = TOFF + (BLOCK / 64) * (kPoolWords * 64) + (CNT ? (BLOCK / 64) * kCountQueue + kSatTags + TBL / 8 : 0);
+    constexpr int SOFF = Lds::stacks;
+    static_assert(Lds::total == SOFF + NS * BLOCK, "the ancestor stacks are the last LDS region (see StackLds)");
     static_assert(D == 23, "2^D + code must be an f32 with unit spacing");
     constexpr float kScale = (float)(1 << (D - 1));  // 2^22: grid units per unit of the cube
     constexpr float kInvScale = 1.0f / kScale;
@@ -1139,7 +1155,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                         Dr2 = __uint_as_float(pool[5 * 64 + e]);
                         // RN(1 / Dr), what div_by_recip wants, recomputed here instead of three more words per pooled ray (8 words keep a
                         // workgroup at 22 KiB of LDS): v_rcp_f32 and one Newton step give the correctly rounded reciprocal for every
-                        // f32 of a clean ray's range (tools/rcptest_gpu.hip: all 2.85e9 of them, profiles/r04_rcptest.log)
+                        // f32 of a clean ray's range (tools/rcptest_gpu.hip: all 1.43e9 of them, profiles/r04_rcptest.log; tests/test_lds_oob_gpu.py re-runs it)
                         Y0 = recip_rn(Dr0);
                         Y1 = recip_rn(Dr1);
                         Y2 = recip_rn(Dr2);
@@ -1213,7 +1229,9 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             // table stands for them), are reported until the table knows them -- a compare-and-swap that finds a 15 does nothing.
             // Final counters = min(15, old + visits), like the RESTART kernel.
             // (Wave-uniform control flow around per-lane predicates: the queue cursor is a scalar.)
-            const bool at_leaf = sabs(stf) == ST_LEAF;
+            // (a lane whose walk ended below level SMAX -- a tree deeper than declared: its ray ends with the "too deep" record and the frame
+            // is refused -- reports no visits: ADVICE r4)
+            const bool at_leaf = sabs(stf) == ST_LEAF && !(kWalkTrips && __uint_as_float(sh) < kMagic + (float)(D - SMAX));
             const uint64_t c_c0 = DBGH ? __builtin_amdgcn_s_memtime() : 0ull;
             if (__ballot(at_leaf) != 0ull) {
                 const uint32_t L = min((uint32_t)D - sh_of(sh), (uint32_t)SMAX);  // (a word below level SMAX ends the ray: the tree is deeper than declared)
@@ -1877,7 +1895,6 @@ hipError_t launch_build_top_table(const uint32_t *nodes, uint32_t n_words, uint3
 constexpr int kStackBlock = 256;
 constexpr int kStackLevels = 12;      // default: resolves levels up to 3 + 1 + 12 = 16
 constexpr int kStackLevelsDeep = 18;  // deep trees: up to level 22 = kPathBits - 1
-constexpr int kPoolWordsHost = kPoolWords;
 
 int stack_max_depth(bool deep) { return kTopLevels + 1 + (deep ? kStackLevelsDeep : kStackLevels); }
 
@@ -1892,9 +1909,8 @@ static hipError_t launch_stack(const TraceArgs &args, const LaunchInfo &li, hipS
                                          : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, true, false>)
                            : (args.debug ? trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, true, false, false>
                                          : trace_stack_kernel<kStackBlock, NS, kTopLevels, GE, false, false, false>));
-    // (64: the walk's bit-spreading table, kLutWords in the kernel -- every instantiation reserves it; the stacks stay the last region)
-    size_t lds_bytes = (size_t)((SVO_TOP_IN_LDS ? (1 << (3 * kTopLevels)) : 0) + 64 + NS * kStackBlock + (kStackBlock / 64) * kPoolWordsHost * 64 +
-                                (args.count_nodes ? (kStackBlock / 64) * kCountQueue + kSatTags + (1 << (3 * kTopLevels)) / 8 : 0)) * sizeof(uint32_t);
+    const size_t lds_bytes = sizeof(uint32_t) * (size_t)(args.count_nodes ? StackLds<kStackBlock, NS, kTopLevels, true>::total
+                                                                               : StackLds<kStackBlock, NS, kTopLevels, false>::total);
     // cached per context (= per device): [deep stack?][fused shadows?][counting instantiation?]
     int &blocks_per_cu = li.occupancy[(args.debug ? 8 : 0) + (NS == kStackLevelsDeep ? 4 : 0) + (shd ? 2 : 0) + (args.count_nodes ? 1 : 0)];
     if (blocks_per_cu == 0) {

@@ -290,7 +290,8 @@ __device__ __forceinline__ float div_by_recip(float a, float d, float y) {
 }
 
 // RN(1 / d) for 2^-20 <= |d| <= 2^64: the hardware reciprocal (1 ulp) and one Newton step; equal to the IEEE division for every
-// such d (tools/rcptest_gpu.hip compares all of them; SVO_RECIP_IEEE=1 builds the division instead)
+// such d ON gfx950 (tools/rcptest_gpu.hip compares all of them -- tests/test_lds_oob_gpu.py runs it on the GPU under test --; svo_kernels.hip
+// refuses to build for another target; SVO_RECIP_IEEE=1 builds the division instead)
 #ifndef SVO_RECIP_IEEE
 #define SVO_RECIP_IEEE 0
 #endif

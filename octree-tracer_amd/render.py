@@ -95,6 +95,14 @@ class Render:
     def update(self, settings, character):
         """render.rs:191-215: camera = proj * look_at_rh; upload the uniforms."""
         w, h = self.size
+        # Settings.octree_depth (app.rs:24) is the depth the adaptive loop refines to: a tree may reach it, so it is declared to the
+        # library when it exceeds the default kernel's 16 levels (SVO_OPT_TREE_DEPTH; never lowered here -- ADVICE r4: a deeper
+        # scene used to fail only at svo_sync)
+        depth = int(getattr(settings, "octree_depth", 0) or 0)
+        if depth > 16 and depth > getattr(self, "_declared_depth", 16):
+            from .gpu import OPT_TREE_DEPTH
+            self.gpu.set_option(OPT_TREE_DEPTH, depth)
+            self._declared_depth = depth
         cam, inv = camera_matrices(character.pos, character.look, settings.fov, w, h)
         self.uniforms.camera[:] = cam.tolist()
         self.uniforms.camera_inverse[:] = inv.tolist()

@@ -671,6 +671,10 @@ static void par_for(void (*fn)(void *, size_t, size_t), void *arg, size_t n, siz
     size_t n_chunks = (n + j.chunk - 1) / j.chunk;
     if ((size_t)n_threads > n_chunks) n_threads = n_chunks ? (int)n_chunks : 1;
     if (n_threads == 1) { par_run(&j); return; }
+    /* the pool has ONE job slot: concurrent callers -- two Python threads are enough, ctypes releases the GIL around a call -- take
+     * turns for the whole of their job */
+    static pthread_mutex_t submit = PTHREAD_MUTEX_INITIALIZER;
+    pthread_mutex_lock(&submit);
     pthread_mutex_lock(&par_pool.mu);
     if (!par_pool.atfork) { pthread_atfork(NULL, NULL, par_after_fork_child); par_pool.atfork = 1; }
     while (par_pool.n_workers < n_threads - 1) {
@@ -689,6 +693,7 @@ static void par_for(void (*fn)(void *, size_t, size_t), void *arg, size_t n, siz
     while (par_pool.busy != 0) pthread_cond_wait(&par_pool.done, &par_pool.mu);
     par_pool.job = NULL;
     pthread_mutex_unlock(&par_pool.mu);
+    pthread_mutex_unlock(&submit);
 }
 
 typedef struct {

@@ -27,3 +27,18 @@ def test_lds_accesses_beyond_the_allocation_are_dropped(tmp_path):
     # 4096 workgroups x 50 rounds: the only out-of-range reads that may see data are those inside the 1280-byte granule the
     # 1024-byte allocation is rounded up to (offsets 1024 .. 1279: 64 threads)
     assert nonzero <= 4096 * 50 * 64, out
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
+def test_rcp_plus_one_newton_step_is_the_ieee_reciprocal(tmp_path):
+    """Bit-exact parity of the pick-up's RN(1 / Dr) (svo_trace_fn.h: recip_rn) rests on gfx950's v_rcp_f32 followed by one Newton step
+    being the correctly rounded reciprocal for every f32 of a clean direction's range: all 85 binades x 2^24 values, on the GPU that
+    runs the suite (this was a manual tool)."""
+    exe = str(tmp_path / "rcptest")
+    src = os.path.join(ROOT, "tools", "rcptest_gpu.hip")
+    subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-o", exe, src], check=True, timeout=600, capture_output=True)
+    res = subprocess.run([exe], timeout=300, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    m = re.search(r"= (\d+) values, (\d+) mismatches", res.stdout)
+    assert m and int(m.group(1)) == 85 << 24 and int(m.group(2)) == 0, res.stdout
