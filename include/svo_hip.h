@@ -97,7 +97,7 @@ typedef enum svo_option {
     SVO_OPT_VARIANT = 0,
     SVO_OPT_TIMING = 1,      /* n > 0: bracket trace launches with HIP events on the launch stream (ring of n) */
     SVO_OPT_GRID_BLOCKS = 2, /* persistent grid size override (0 = auto) */
-    SVO_OPT_REFILL_MIN = 3,  /* idle lanes needed before a wave refills */
+    SVO_OPT_REFILL_MIN = 3,  /* idle lanes needed before a wave refills (default 32 since round 5) */
     SVO_OPT_STRIP_ITEMS = 4, /* pixel slots a wave claims at a time (multiple of 64) */
     SVO_OPT_DYNAMIC_STRIPS = 5, /* accepted and ignored: the STACK kernel always claims its strips from device counters (the static
                                 round-robin deal of round 1 cost the hot loop scalar registers) */
@@ -110,8 +110,10 @@ typedef enum svo_option {
                                 completes, svo_sync returns SVO_ERR_STATE (svo_last_error says so) and the frame's records are not to be used
                                 (tests/test_parity_gpu.py: test_tree_deeper_than_declared_is_refused) */
     SVO_OPT_BLOCK_SHAPE = 10, /* log2 of the width of the 64-pixel blocks a wave works on (3: 8x8, 4: 16x4, ...) */
-    SVO_OPT_DEBUG_BUFFER = 7, /* device pointer receiving 16 words per wave: start, queue-dry, end (10 ns ticks), rounds, ...,
-                                 shader cycles per phase (refill, descent, step), descent-loop shape (tools/wave_timeline.py) */
+    SVO_OPT_DEBUG_BUFFER = 7, /* device pointer to 2 x 16384 x 16 words.  First region, 16 words per wave: start, queue-dry, end (10 ns
+                                 ticks), rounds, ..., shader cycles per phase (refill, descent, step), descent-loop shape; second region
+                                 (round 5), 16 words per wave: loop entry, the first 14 ray generations (10 ns ticks), XCC / hardware id
+                                 (tools/wave_timeline.py, tools/timeline_by_xcd.py) */
     SVO_OPT_SCAN_CLEARS_COUNTERS = 11, /* 1: svo_scan_dispatch also zeroes the hit counters it has scanned, so that the
                                           host need not re-upload the whole array to reset them (svo_nodes_scatter) */
     SVO_OPT_FUSED_SHADOWS = 12, /* shaded frames with shadows (svo_render* with rgba_out), STACK variant: 1 = the lane that finds a hit goes

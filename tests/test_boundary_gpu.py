@@ -178,11 +178,17 @@ def test_bench_multi_gpu_line_carries_both_wires(pkg, gpu):
     also = cfg["also_rgba8"]
     assert also["value"] > 0 and also["image_matches_oracle_fs_main_within_1_code_value"] is True
     assert cfg["one_gpu_same_workload"]["value"] > 0
+    # the colour wire has a like-for-like one-GPU denominator (trace + shade), and the line says on which wire
+    # the >= 6x target is to be read
+    assert cfg["one_gpu_same_workload_rgba8"]["value"] > 0 and "shades" in cfg["one_gpu_same_workload_rgba8"]["what"]
+    assert cfg["one_gpu_same_workload_rgba8"]["value"] < cfg["one_gpu_same_workload"]["value"] * 1.05, "tracing and shading cannot be faster than tracing"
+    assert "also_rgba8" in cfg["scaling_read_on"] and "one_gpu_same_workload_rgba8" in cfg["scaling_read_on"]
     lb = cfg["link_bound"]
     assert lb["links_into_rank0"] == 1 and lb["packed12"]["bytes_into_rank0_per_frame"] == 1920 * 1080 * 12 // 2
     assert lb["rgba8"]["max_mrays_s"] == pytest.approx(3 * lb["packed12"]["max_mrays_s"], rel=1e-3)
     k4 = cfg["also"]
     assert k4["workload"] == "terrain16_4k" and k4["value"] > 0 and k4["also_rgba8"]["value"] > 0 and k4["one_gpu_same_workload"]["value"] > 0
+    assert k4["one_gpu_same_workload_rgba8"]["value"] > 0 and "scaling_read_on" in k4
     assert k4["link_bound"]["packed12"]["bytes_into_rank0_per_frame"] == 3840 * 2160 * 12 // 2
 
 
@@ -195,6 +201,9 @@ def test_bench_line_fields(pkg, gpu):
     assert cfg["cold_frame_ms"] > 0 and cfg["motion_ms"] > 0 and cfg["also"]["workload"] == "terrain16_4k" and cfg["also"]["value"] > 0
     assert line["roofline"]["bound"] == "hbm" and "traffic_source" in line["roofline"] and line["roofline"]["measured_hbm_gbs"] > 0
     assert 0 < line["roofline_valu"]["frac"] < 1
+    # the issue peak at the clock held inside the kernel, and the fractions of the frames that are not the best case
+    assert 1.5 < line["roofline_valu"]["shader_clock_ghz_in_kernel"] <= 2.4 and line["roofline_valu"]["peak"] <= line["roofline_valu"]["peak_at_2p4_ghz"]
+    assert 0 < line["roofline"]["frac_cold"] <= line["roofline"]["frac"] * 1.02 and 0 < line["roofline"]["frac_motion"] <= line["roofline"]["frac"] * 1.02
     assert line["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] is True
     assert line["cpu_baseline"]["host_cores_total"] >= line["cpu_baseline"]["cores"]
 

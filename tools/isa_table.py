@@ -94,7 +94,7 @@ def main():
     # per section of the round, by where the source line lies (lambdas are inlined: their lines say what they belong to)
     def find(marker):
         return next(i + 1 for i, l in enumerate(src_lines) if marker in l)
-    marks = [("restart_at (end of the step: where the next walk starts)", find("auto restart_at = [&]")),
+    marks = [("restart_at (end of the step: where the next walk starts)", find("auto restart_at_rb = [&]")),
              ("flush_record (refill: the record of a finished ray)", find("auto flush_record = [&]")),
              ("walk (descend)", find("auto descend = [&]")),
              ("camera shortcut set-up (before the loop)", find("// Camera shortcut.")),
