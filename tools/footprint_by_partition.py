@@ -110,3 +110,23 @@ for name, f in (("classes 4..7 merged", lambda c: np.where((c >= 4) & (c < 8), 4
     cls = f(cls_orig)
     footprint(lists_colmajor(1), "column-major, " + name)
 cls = cls_orig
+# one common set of cuts for the classes below `lo`, per-class cuts from `lo` up (what strip_order_kernel can do with its rank compare)
+def lists_common_below(lo):
+    rows=H//8
+    bx=np.arange(ns)%bpr; by=np.arange(ns)//bpr
+    pos=bx*rows+by
+    order=np.argsort(pos,kind='stable')
+    lst=np.zeros(ns,dtype=np.int64)
+    low=order[cls[order]<lo]; n=len(low); sl=max((n+7)//8,1); lst[low]=np.minimum(np.arange(n)//sl,7)
+    for c in range(lo,32):
+        idx=order[cls[order]==c]; n=len(idx)
+        if n: sl=max((n+7)//8,1); lst[idx]=np.minimum(np.arange(n)//sl,7)
+    L=[]
+    for l in range(8):
+        mine=np.nonzero(lst==l)[0]
+        key=(31-cls[mine])*ns + pos[mine]
+        L.append(mine[np.argsort(key,kind='stable')].tolist())
+    return L
+for lo in (15, 12, 8):
+    L=lists_common_below(lo); footprint(L,f"common cuts below class {lo}")
+    print("    per list: class>=15", [int((cls[l]>=15).sum()) for l in L], "class 8..14", [int(((cls[l]>=8)&(cls[l]<15)).sum()) for l in L], "class 4..7", [int(((cls[l]>=4)&(cls[l]<8)).sum()) for l in L], "class<4", [int((cls[l]<4).sum()) for l in L])
