@@ -1097,7 +1097,9 @@ def test_bench_multi_gpu_path_with_one_rank(pkg, gpu):
     assert r.returncode == 0, r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] is True
-    assert line["config"]["frames_in_flight"] == 3 and "12 B/ray" in line["config"]["sharding"]
+    # (three lanes exist; a rank's share of 0.7 M rays or more -- here the whole frame -- runs two deep since round 5: bench.py)
+    assert line["config"]["frames_in_flight"] == 2 and line["config"]["frames_in_flight_by_frame_size"]["1920x1080"] == 2
+    assert "12 B/ray" in line["config"]["sharding"]
     assert line["steps"] == 24 and line["value"] > 100
     # the same path carrying the shaded colour frame instead of records (4 bytes per ray on the links)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-pipeline", "--wire", "rgba8", "--steps", "12", "--warmup", "2",
