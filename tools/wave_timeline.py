@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--w", type=int, default=1920)
     ap.add_argument("--h", type=int, default=1080)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--cold", action="store_true", help="the measured frame is the first of a layout: its strip schedule is dropped just before (static tree only)")
     ap.add_argument("--raw", default=None, help="save the per-wave words (timeline, events) as .npz")
     ap.add_argument("--count", action="store_true", help="hit counters live, cleared before the frame (the reference's default mode)")
     ap.add_argument("--carry", action="store_true", help="with --count: the counters carry over from frame to frame (no scan in between)")
@@ -78,6 +79,8 @@ def main():
     gpu.set_option(pkg.gpu.OPT_DEBUG_BUFFER, dbg.data_ptr())
     for _ in range(2):  # (the first launch of the timeline instantiation starts seven of the eight XCDs 100 us late: its scratch memory is set up then)
         dbg.zero_()
+        if a.cold:
+            gpu.set_option(pkg.gpu.OPT_SCHEDULE, 2)  # (setting the period forgets the schedule)
         render.render(hits=hits)
         ms = gpu.last_render_ms()
         gpu.sync()
