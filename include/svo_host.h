@@ -152,6 +152,11 @@ uint64_t svo_gen_random(uint32_t seed, uint32_t max_depth, float p_split, float 
                         uint32_t *out, uint64_t cap);
 /* maximum leaf depth of a node array (BFS over the array; 0 for malformed) */
 uint32_t svo_nodes_max_depth(const uint32_t *words, uint64_t n);
+/* Re-linearisation (round 5): the same tree with its child groups reordered -- levels 1 .. block_level breadth-first, then every subtree
+ * below a level-block_level interior word as one contiguous block.  out: >= n words; perm (optional, >= n words): perm[new word] = old
+ * word.  Returns the words written (unreachable words are dropped), 0 for a malformed tree.  The reference has no counterpart: its
+ * loaders emit insertion order (.vox, cpu_octree.rs:100-111) or breadth-first order (.rsvo, :160-172). */
+uint64_t svo_nodes_relayout(const uint32_t *words, uint64_t n, uint32_t block_level, uint32_t *out, uint32_t *perm);
 
 #ifdef __cplusplus
 }

@@ -57,7 +57,7 @@ HOST_SYMBOLS = [
     "svo_world_chunk", "svo_world_chunk_ids", "svo_world_find_voxel", "svo_world_generate_mip_tree",
     "svo_world_save_chunk", "svo_world_load_chunk", "svo_world_load", "svo_cpu_octree_bin", "svo_cpu_octree_from_bin",
     "svo_adaptive_subdivide", "svo_adaptive_unsubdivide", "svo_world_expand",
-    "svo_gen_terrain", "svo_gen_terrain_height", "svo_gen_fractal", "svo_gen_random", "svo_nodes_max_depth",
+    "svo_gen_terrain", "svo_gen_terrain_height", "svo_gen_fractal", "svo_gen_random", "svo_nodes_max_depth", "svo_nodes_relayout",
 ]
 
 _lib = None
@@ -180,6 +180,7 @@ def lib():
     sig("svo_gen_fractal", u64, C.POINTER(TerrainParams), vp, u64)
     sig("svo_gen_random", u64, u32, u32, f32, f32, u64, vp, u64)
     sig("svo_nodes_max_depth", u32, vp, u64)
+    sig("svo_nodes_relayout", u64, vp, u64, u32, vp, vp)
     _lib = L
     return L
 

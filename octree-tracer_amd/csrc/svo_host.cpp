@@ -1116,6 +1116,60 @@ uint64_t svo_gen_random(uint32_t seed, uint32_t max_depth, float p_split, float 
     return b.n;
 }
 
+// Re-linearisation of a node array: the same tree, its child groups in another order.  Groups of the levels
+// 1 .. block_level in breadth-first order first (what the reference's .rsvo loader and this repository's generators emit for the whole
+// tree), then every subtree below a level-`block_level` interior word as ONE contiguous block, breadth-first inside: the levels a ray walks
+// below that word lie within one block instead of one region of the array per level.  out: the new array (at most n words: words that are
+// not reachable from the root are dropped); perm (optional): perm[new word] = old word, so that a hit's voxel index can be translated
+// back.  Returns the number of words written, 0 for a malformed tree (pointer out of range, deeper than 31 levels, a cycle).
+uint64_t svo_nodes_relayout(const uint32_t *words, uint64_t n, uint32_t block_level, uint32_t *out, uint32_t *perm) {
+    if (!words || !out || n < 8) return 0;
+    std::vector<uint32_t> order;           // old group start of the k-th group of the new array
+    order.reserve(n / 8);
+    std::vector<uint32_t> cur{0u}, next, roots;  // BFS frontier (old group starts); subtree roots found at block_level
+    for (uint32_t level = 1; !cur.empty(); level++) {
+        if (level > 31) return 0;
+        next.clear();
+        for (uint32_t g : cur) {
+            if (uint64_t(g) + 8 > n || order.size() >= n / 8) return 0;
+            order.push_back(g);
+            for (uint32_t c = 0; c < 8; c++) {
+                const uint32_t ptr = words[g + c] >> 4;
+                if (ptr < kVoxelOffset) (level == block_level ? roots : next).push_back(ptr);
+            }
+        }
+        cur.swap(next);
+    }
+    for (uint32_t r : roots) {  // one block per subtree, breadth-first inside
+        cur.assign(1, r);
+        for (uint32_t level = block_level + 1; !cur.empty(); level++) {
+            if (level > 31) return 0;
+            next.clear();
+            for (uint32_t g : cur) {
+                if (uint64_t(g) + 8 > n || order.size() >= n / 8) return 0;
+                order.push_back(g);
+                for (uint32_t c = 0; c < 8; c++) {
+                    const uint32_t ptr = words[g + c] >> 4;
+                    if (ptr < kVoxelOffset) next.push_back(ptr);
+                }
+            }
+            cur.swap(next);
+        }
+    }
+    std::vector<uint32_t> new_of(n / 8 + 1, 0xFFFFFFFFu);  // old group number -> new group start
+    for (size_t k = 0; k < order.size(); k++) {
+        if (order[k] % 8u != 0u || new_of[order[k] / 8u] != 0xFFFFFFFFu) return 0;  // (groups are 8-aligned in every array this library builds; a group reached twice: not a tree)
+        new_of[order[k] / 8u] = uint32_t(k * 8);
+    }
+    for (size_t k = 0; k < order.size(); k++)
+        for (uint32_t c = 0; c < 8; c++) {
+            const uint32_t w = words[order[k] + c], ptr = w >> 4;
+            out[k * 8 + c] = ptr < kVoxelOffset ? ((new_of[ptr / 8u] << 4) | (w & 15u)) : w;
+            if (perm) perm[k * 8 + c] = order[k] + c;
+        }
+    return uint64_t(order.size()) * 8;
+}
+
 uint32_t svo_nodes_max_depth(const uint32_t *words, uint64_t n) {
     if (!words || n < 8) return 0;
     std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 1u}};

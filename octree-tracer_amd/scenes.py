@@ -52,3 +52,14 @@ def terrain_camera(seed=0, max_depth=16, x=0.05, z=-0.6, eye_height=0.004, look=
 def max_depth(words):
     words = np.ascontiguousarray(words, dtype=np.uint32)
     return lib().svo_nodes_max_depth(words.ctypes.data, words.size)
+
+
+def relayout(words, block_level=10, with_perm=False):
+    """svo_nodes_relayout: the same tree, levels 1 .. block_level breadth-first, every subtree below as one contiguous block."""
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    out = np.empty(words.size, dtype=np.uint32)
+    perm = np.empty(words.size, dtype=np.uint32) if with_perm else None
+    n = lib().svo_nodes_relayout(words.ctypes.data, words.size, block_level, out.ctypes.data, perm.ctypes.data if with_perm else None)
+    if n == 0:
+        raise ValueError("svo_nodes_relayout: malformed tree")
+    return (out[:n], perm[:n]) if with_perm else out[:n]

@@ -271,3 +271,28 @@ def test_vox_without_rgba_chunk_uses_the_default_palette(pkg, O):
     # colour value = R << 16 | G << 8 | B (cpu_octree.rs:204 via Voxel::to_value)
     j = 36  # file index 37 -> cube entry j = 36: R = 0xff - 0x33, G = B = 0xff
     assert leaves == sorted([0xFFFFFF, 0xEE0000, 0x111111, (0xFF - 0x33) << 16 | 0xFF << 8 | 0xFF])
+
+
+def test_relayout_keeps_the_tree_and_translates_indices_back(pkg, O, monu9_words):
+    """svo_nodes_relayout (round 5): the child groups of a tree in another order -- upper levels breadth-first, every subtree below
+    block_level as one contiguous block -- is the same tree: every ray's record is the same but for the voxel index, and the permutation
+    it returns translates that back.  Trees of three builders, several block levels; unreachable padding is dropped."""
+    terrain = pkg.scenes.terrain(seed=2, max_depth=12, cam=(0.1, 0.3, -0.2), lod_c=300.0, max_words=3_000_000)
+    random9 = pkg.scenes.random_tree(seed=5, max_depth=9, p_split=0.55, p_solid=0.25, max_words=1 << 20)
+    u = O.make_uniforms((0.1, 0.3, -0.2), (0.0, -0.3, 1.0), 90.0, 160, 90)
+    for words, levels in ((terrain, (1, 6, 10, 31)), (random9, (3, 8)), (np.asarray(monu9_words), (2, 5))):
+        want = O.trace_frame(words, u, threads=4).reshape(-1)
+        for b in levels:
+            out, perm = pkg.scenes.relayout(words, b, with_perm=True)
+            assert out.size == words.size and pkg.scenes.max_depth(out) == pkg.scenes.max_depth(words)
+            assert np.array_equal(np.sort(perm), np.arange(words.size)), "a permutation of the words"
+            got = O.trace_frame(out, u, threads=4).reshape(-1)
+            assert np.array_equal(got["t"], want["t"]) and np.array_equal(got["info"], want["info"]) and np.array_equal(got["normal_bits"], want["normal_bits"])
+            real = want["value"] < words.size
+            assert np.array_equal(perm[got["value"][real]], want["value"][real]) and np.array_equal(got["value"][~real], want["value"][~real])
+    padded = np.concatenate([terrain, np.zeros(64, dtype=np.uint32)])
+    assert pkg.scenes.relayout(padded, 6).size == terrain.size
+    bad = terrain.copy()
+    bad[0] = (bad.size + 8) << 4  # a pointer past the array
+    with pytest.raises(ValueError):
+        pkg.scenes.relayout(bad, 6)

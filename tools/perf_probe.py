@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--claim-at", default="64")
     ap.add_argument("--tail", default="0")
     ap.add_argument("--pose", type=int, default=0)
+    ap.add_argument("--relayout", type=int, default=0, help="re-linearise the node array first (svo_nodes_relayout): subtrees below this level as contiguous blocks")
     ap.add_argument("--motion", type=float, default=0.0, help="degrees of yaw added to the camera every frame")
     a = ap.parse_args()
     pkg = entry.load_package()
@@ -53,6 +54,8 @@ def main():
             cam, look = poses[1 if a.scene == "config3b" else 0]
         else:
             cam, look = cs.config2(pkg)[1][a.pose]
+    if a.relayout:
+        words = pkg.scenes.relayout(words, a.relayout)
     print(f"scene {a.scene}: {words.size} words ({words.size * 4 / 1e6:.1f} MB) built in {time.time() - t0:.1f}s", flush=True)
     gpu = pkg.Gpu(0)
     render = pkg.Render(gpu, (a.w, a.h), words, capacity=words.size)
