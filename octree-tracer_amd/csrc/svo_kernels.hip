@@ -1028,6 +1028,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                 // strip).  Probing the counters one atomic after the other would cost a finished wave 64 round trips to find
                 // out that the frame is over.
                 while (s == 0xFFFFFFFFu) {
+                    if (DBG && !DBGH && lane == 0u) dbg_desc_iters += 1u;  // (light timeline build, slot 12: probes of the 64 claim counters)
                     const uint32_t l = lane / kSubs;
                     const uint32_t cv = __hip_atomic_load(work_counter + lane * kShardStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t res_l = ((gridDim.x + kShards - 1u - l) / kShards) * (uint32_t)(BLOCK / 64);

@@ -118,6 +118,7 @@ def main():
                      "flush_cycles_per_round": round(float(d[:, 13].sum() / max(rounds, 1)), 1), "flushes_per_wave": round(float(d[:, 14].mean()), 2)} if a.count else None,
         "claim_wait_cycles_per_wave": int(d[:, 15].mean()) if not a.count else None,
         # (light build: slot 14 = cycles until the claim's answer is there, slot 15 = the same plus the schedule-list look-ups)
+        "counter_probes_per_wave_pct": np.percentile(d[:, 12], pct).round(0).tolist(), "counter_probes_total": int(d[:, 12].sum()),  # (light build only)
         "claim_answer_cycles_pct": np.percentile(d[:, 14], pct).round(0).tolist(), "claim_total_cycles_pct": np.percentile(d[:, 15], pct).round(0).tolist(),
         "cycles_per_generated_strip": round(float(d[:, 11].sum() / max(d[:, 7].sum(), 1)), 1),
         "shader_clock_ghz_in_kernel": round(float(np.median(life_cyc / np.maximum((d[:, 2] - d[:, 0]) * 10.0, 1))), 3),
