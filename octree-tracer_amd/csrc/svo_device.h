@@ -15,7 +15,15 @@ constexpr int kTopEntries = 1 << (3 * kTopLevels);
 constexpr int kTopAuxEntries = 8 + 64;  // level-1 and level-2 cells -> child group of the next level (kTopLevels = 3)
 constexpr int kPathBits = 23;                  // D: path-code bits per axis (grid units: 2^(D-1) per unit of the reference's cube, so that
                                                // 2^D + code is an exact f32 whose mantissa IS the code: DESIGN.md 4.2)
-constexpr int kCounterWords = 2048;            // 64 claim counters (8 lists x 8 counters), one per 128-byte line
+// Words between two claim counters.  Rounds 2 - 4 kept them 128 B apart (all 64 within 8 KB); round 5: 64 KB + 128 B apart.  Every claim is
+// an atomic executed at the memory side, and while one is in flight the L2 channel it went through answers everything else more slowly
+// (profiles/r05_pmc_claim_timing_ab.json) -- 8 KB of counters sit behind one or two channels, 4 MB of them behind all
+// (profiles/r05_counter_stride_ab*.log: 1080p -1.1 / -3.4 %, 4K -1.6 / -0.3 % in two runs; 4 KB + 128 B: -0.5 / -2.5 %, -0.7 / -1.2 %)
+#ifndef SVO_COUNTER_STRIDE
+#define SVO_COUNTER_STRIDE 16416
+#endif
+constexpr int kCounterStride = SVO_COUNTER_STRIDE;
+constexpr int kCounterWords = 64 * kCounterStride;  // 64 claim counters (8 lists x 8 counters)
 
 // Top-table entry (one per level-K cell, index = cx << 2K | cy << K | cz): level << 27 | child group index.
 // The level is K+1 below an interior cell, or the shallower level at which a leaf covers the whole cell

@@ -37,6 +37,9 @@
 #ifndef SVO_WALK_LUT   // 1: the walk takes the child indices of six levels at a time from one register built with three LDS look-ups (a 64-entry
 #define SVO_WALK_LUT 2  // bit-spreading table) instead of three bit-field extracts and two shift-ors per level (default kernel, static tree)
 #endif
+#ifndef SVO_WALK_LUT_CNT   // the same walk in the counting instantiations (hit counters live), the saturation notes as one carry bit per level
+#define SVO_WALK_LUT_CNT 1
+#endif
 #ifndef SVO_DBG_LIGHT   // 1: the timeline instantiation records only its time stamps (start, loop entry, generations, dry, end) and runs the
 #define SVO_DBG_LIGHT 0  // product's hand-written walk at the product's occupancy: a progress curve that is not distorted by the phase clocks
 #endif
@@ -89,6 +92,16 @@ __device__ __forceinline__ uint32_t visit_groups(uint32_t n_words, uint32_t p, u
     const uint64_t needmask = __ballot(need);
     if (!needmask) return 0u;
     const uint32_t lane = __lane_id();
+    if (RUNS_ONLY) {
+        // (round 5, half the instructions of the general form below: lanes with nothing to report carry an index no word has, so "the
+        // lane below reports another word" is one compare; a run ends at the next head or idle lane above -- or at lane 64: the mask
+        // of those, shifted down to this lane, always has a lowest bit)
+        const uint32_t pm = need ? p : 0xFFFFFFFFu;
+        const uint32_t under = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)pm, 0x138, 0xF, 0xF, false);  // (DPP wave_shr:1; lane 0 keeps the -1)
+        const bool head = need && under != pm;
+        const uint64_t stop = ((((uint64_t)__ballot(head) | ~needmask) >> 1) | (1ull << 63)) >> lane;  // bit j: the run ends below lane + 1 + j
+        return head ? (uint32_t)__builtin_ctzll(stop) + 1u : 0u;
+    }
     // p of lane - 1 (DPP wave_shr:1: a shuffle through the LDS pipe costs its latency); only looked at when lane - 1 is in needmask
     const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x138, 0xF, 0xF, false);
     const bool head = need && (lane == 0u || !((needmask >> (lane - 1u)) & 1ull) || prev != p);
@@ -332,7 +345,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     constexpr int kLutWords = 64;
     constexpr int LOFF = Lds::lut;
     constexpr int TOFF = Lds::pools;  // LDS words in front of the ray pools
-    constexpr bool kLut = SVO_WALK_LUT != 0 && NS <= 12 && !CNT;
+    constexpr bool kLut = SVO_WALK_LUT != 0 && NS <= 12 && (!CNT || SVO_WALK_LUT_CNT != 0);
     constexpr int SOFF = Lds::stacks;
     static_assert(Lds::total == SOFF + NS * BLOCK, "the ancestor stacks are the last LDS region (see StackLds)");
     static_assert(D == 23, "2^D + code must be an f32 with unit spacing");
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
     // dealt round-robin over the 8 XCDs, so the waves sharing an L2 work on one screen region and walk it in
     // order -- and moves on to the next region when its own is exhausted (work stealing keeps the tail short;
     // a single counter would serialise at ~88 claims/us).  Static mode: strips dealt round-robin to waves.
-    constexpr uint32_t kShards = 8, kShardStride = 32;  // counters 128 B apart
+    constexpr uint32_t kShards = 8, kShardStride = (uint32_t)kCounterStride;  // (svo_device.h: 64 KB + 128 B apart)
     // Every list has kSubs claim counters, each handing out every kSubs-th of the list's entries (counter j: entries
     // reserved + j, reserved + j + kSubs, ...: every counter walks the whole list, longest strips first); a wave starts
     // with counter (blockIdx / kShards) % kSubs of its list, takes the list's counters in turn, and moves on to the next
@@ -754,7 +767,8 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                     pos = 15;
                 }
                 first_word = false;
-                if (CNT) satm |= ((w & 15u) == 15u ? 1u : 0u) << (((uint32_t)D - sh_of(sh)) & 31u);  // (a counter never goes down within a frame)
+                // (a counter never goes down within a frame; the hand-written loop of the look-up-table walk takes its notes itself, see satb)
+                if (CNT && !(kWalkAsm && kLut)) satm |= ((w & 15u) == 15u ? 1u : 0u) << (((uint32_t)D - sh_of(sh)) & 31u);
                 c = child_below();  // (sh now points one level below the word in flight)
                 if (kLut) asm volatile("" : "+v"(c));  // (before the wait for the word, not behind it)
                 // sign bit: a leaf (word >= VOXEL_OFFSET << 4), or level SMAX reached (deeper trees are refused)
@@ -767,11 +781,67 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             // allocation (see SOFF).  A word found below level SMAX is handed on as an interior word, which is what the walk of rounds
             // 1-3 stopped at: the ray ends there with the "too deep" record and svo_sync reports the frame.
             uint32_t trips = (uint32_t)NS;
+            uint32_t satb = 0u;  // CNT, look-up-table walk: one saturation bit per word the hand-written loop has gone through, the last one lowest
             if (kWalkAsm) {
                 // The same loop as below, instruction for instruction, but for its control: the compiler keeps the lanes that have
                 // left in a second mask and folds the count's flag into it -- four scalar instructions between a word's arrival
                 // and the next load; every instruction there costs the walk its latency (profiles/r04_walk_critical_path_ab.log).
-                if (CNT && (int32_t)w >= 0) {
+                if (CNT && kLut && (int32_t)w >= 0) {
+                    // (hit counters live, look-up-table walk: the loop of the kLut branch below plus the saturation note of the word that has
+                    // just arrived -- three instructions: its counter bits, a compare, and satb = 2 satb + carry.  After n iterations bit
+                    // n - 1 - i of satb belongs to the word of iteration i; the walk turns them into level bits of satm when it is over.)
+                    uint32_t tmp, cnt4;
+                    uint64_t saved;
+                    asm volatile(
+                        "s_mov_b64 %[sv], exec\n"
+                        "1:\n\t"
+                        "v_and_b32 %[t2], 15, %[w]\n\t"
+                        "v_lshrrev_b32 %[nidx], 4, %[w]\n\t"
+                        "v_add_lshl_u32 %[off], %[nidx], %[c], 2\n\t"
+                        "buffer_load_dword %[w], %[off], %[rs], 0 offen\n\t"
+                        "s_add_i32 %[trips], %[trips], -1\n\t"
+                        "v_cmp_eq_u32 vcc, 15, %[t2]\n\t"
+                        "v_addc_co_u32 %[satb], vcc, %[satb], %[satb], vcc\n\t"
+                        "v_add_u32 %[sp], %[row], %[sp]\n\t"
+                        "v_add_f32 %[sh], -1.0, %[sh]\n\t"
+                        "s_add_i32 %[pos], %[pos], -3\n\t"
+                        "s_cmp_lt_i32 %[pos], 0\n\t"
+                        "s_cbranch_scc1 3f\n"
+                        "4:\n\t"
+                        "v_bfe_u32 %[c], %[m], %[pos], 3\n\t"
+                        "ds_write_b32 %[sp], %[nidx]\n\t"
+                        "s_cmp_eq_u32 %[trips], 0\n\t"
+                        "s_cbranch_scc1 2f\n\t"
+                        "s_waitcnt vmcnt(0)\n\t"
+                        "v_cmp_gt_i32 vcc, 0, %[w]\n\t"
+                        "s_andn2_b64 exec, exec, vcc\n\t"
+                        "s_cbranch_execnz 1b\n\t"
+                        "s_branch 2f\n"
+                        "3:\n\t"
+                        "v_add_f32 %[m], 0xc0e00000, %[sh]\n\t"
+                        "v_lshrrev_b32 %[c], %[m], %[m0]\n\t"
+                        "v_lshrrev_b32 %[t], %[m], %[m1]\n\t"
+                        "v_lshrrev_b32 %[m], %[m], %[m2]\n\t"
+                        "v_and_b32 %[c], 0xfc, %[c]\n\t"
+                        "v_and_b32 %[t], 0xfc, %[t]\n\t"
+                        "v_and_b32 %[m], 0xfc, %[m]\n\t"
+                        "ds_read_b32 %[c], %[c] offset:%[lut]\n\t"
+                        "ds_read_b32 %[t], %[t] offset:%[lut]\n\t"
+                        "ds_read_b32 %[m], %[m] offset:%[lut]\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "v_add_f32 %[m], 0x4b000000, %[m]\n\t"
+                        "v_fmac_f32 %[m], 2.0, %[t]\n\t"
+                        "v_fmac_f32 %[m], 4.0, %[c]\n\t"
+                        "s_mov_b32 %[pos], 15\n\t"
+                        "s_branch 4b\n"
+                        "2:\n\t"
+                        "s_waitcnt vmcnt(0)\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [w] "+v"(w), [nidx] "+v"(nidx), [off] "+v"(off), [c] "+v"(c), [t] "=&v"(tmp), [t2] "=&v"(cnt4), [sp] "+v"(sp), [sh] "+v"(sh),
+                          [m] "+v"(m), [satb] "+v"(satb), [trips] "+s"(trips), [pos] "+s"(pos), [sv] "=&s"(saved)
+                        : [m0] "v"(mu0), [m1] "v"(mu1), [m2] "v"(mu2), [rs] "s"(rs_asm), [row] "s"((uint32_t)(BLOCK * 4)), [lut] "n"(LOFF * 4)
+                        : "vcc", "scc", "memory");
+                } else if (CNT && !kLut && (int32_t)w >= 0) {
                     // (hit counters live: an interior word whose counter has reached 15 is noted in satm, bit = its level, while the
                     // next word travels -- only the counter bits are taken before the load is issued; the word that ends the walk
                     // needs no note: step 3a looks at the leaf's own counter, and bit L is cleared by every restart before it is read)
@@ -811,7 +881,7 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                           [satm] "+v"(satm), [trips] "+s"(trips), [sv] "=&s"(saved)
                         : [m0] "v"(mu0), [m1] "v"(mu1), [m2] "v"(mu2), [rs] "s"(rs_asm), [row] "s"((uint32_t)(BLOCK * 4)), [dm1] "s"((uint32_t)(D - 1))
                         : "vcc", "scc", "memory");
-                } else if (kLut && (int32_t)w >= 0) {
+                } else if (!CNT && kLut && (int32_t)w >= 0) {
                     // (the loop of the next branch with the child index taken from m: one bit-field extract at the scalar position pos;
                     // label 3 is the table look-up for the next six levels, taken when pos runs out -- in the shadow of the load like the rest)
                     uint32_t tmp;
@@ -914,6 +984,8 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                 read_word();
             }
             sh = __float_as_uint(__uint_as_float(sh) + 1.0f);  // back to the leaf's own bit
+            // (the loop's notes: bit j of satb = the word j + 1 levels above the leaf, i.e. level L - 1 - j with L = D - sh; 32 - L = 9 + sh)
+            if (CNT && kWalkAsm && kLut) satm |= __builtin_bitreverse32(satb) >> ((sh + (uint32_t)(32 - D)) & 31u);
             // (a word found below level SMAX -- the tree is deeper than declared -- ends the ray like the interior word the walk of rounds 1-3
             // stopped at; compared as floats: sh may have passed 0)
             const bool below = kWalkTrips && __uint_as_float(sh) < kMagic + (float)(D - SMAX);
@@ -1235,14 +1307,15 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
             const bool at_leaf = sabs(stf) == ST_LEAF && !(kWalkTrips && __uint_as_float(sh) < kMagic + (float)(D - SMAX));
             const uint64_t c_c0 = DBGH ? __builtin_amdgcn_s_memtime() : 0ull;
             if (__ballot(at_leaf) != 0ull) {
-                const uint32_t L = min((uint32_t)D - sh_of(sh), (uint32_t)SMAX);  // (a word below level SMAX ends the ray: the tree is deeper than declared)
+                // (a word below level SMAX ends the ray: the tree is deeper than declared -- with kWalkTrips such a lane is not at_leaf)
+                const uint32_t L = kWalkTrips ? (uint32_t)D - sh_of(sh) : min((uint32_t)D - sh_of(sh), (uint32_t)SMAX);
                 uint32_t todo = at_leaf ? (~satm & ((1u << L) - 2u)) : 0u;  // levels 1 .. L-1 not known to be saturated
                 constexpr uint32_t kTopLv = (2u << K) - 2u;  // levels 1 .. K
-                auto cell_k = [&]() -> uint32_t {
-                    return (__builtin_amdgcn_ubfe(mu0, D - K, K) << (2 * K)) | (__builtin_amdgcn_ubfe(mu1, D - K, K) << K) | __builtin_amdgcn_ubfe(mu2, D - K, K);
+                auto cell_k = [&](uint32_t x0, uint32_t x1, uint32_t x2) -> uint32_t {
+                    return (__builtin_amdgcn_ubfe(x0, D - K, K) << (2 * K)) | (__builtin_amdgcn_ubfe(x1, D - K, K) << K) | __builtin_amdgcn_ubfe(x2, D - K, K);
                 };
                 if (__ballot((todo & kTopLv) != 0u) != 0ull) {  // (rays picked up, rays that crossed a top-level boundary)
-                    const uint32_t cellK = cell_k();
+                    const uint32_t cellK = cell_k(mu0, mu1, mu2);
                     const uint32_t known = (todo & kTopLv) ? ((top_sat[cellK >> 3] >> ((cellK & 7u) * 4u)) & todo & kTopLv) : 0u;
                     satm |= known;
                     todo &= ~known;
@@ -1271,7 +1344,10 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
                         satm |= (1u << l) & ~1u;
                         mine = false;
                         if (l - 1u < (uint32_t)K) {
-                            const uint32_t cellK = cell_k();
+                            uint32_t x0 = mu0, x1 = mu1, x2 = mu2;
+                            // (the cell's arithmetic stays in this rare branch: the compiler had moved it in front of the loop, eight instructions a round)
+                            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
+                            const uint32_t cellK = cell_k(x0, x1, x2);
                             atomicOr(&top_sat[cellK >> 3], (1u << l) << ((cellK & 7u) * 4u));
                         }
                     }
@@ -1566,7 +1642,7 @@ __global__ __launch_bounds__(256) void post_kernel(TraceArgs a, uint32_t *claim_
     // re-arm for the next frame: the claim counters (the trace kernel is done with them) and the deferred
     // count of the OTHER list (this frame's list is still being read by this launch; lists alternate)
     if (blockIdx.x == 0) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)kCounterWords; i += 256u) claim_counters[i] = 0u;
+        for (uint32_t i = threadIdx.x; i < 64u; i += 256u) claim_counters[i * (uint32_t)kCounterStride] = 0u;
         if (threadIdx.x == 0) *next_deferred_count = 0u;
         // (balance_update: n > 0 = the n-th frame fed back: the first steps are large, the later ones small)
         if (a.balance != nullptr && balance_update != 0u) balance_step(a.balance, balance_update <= 6u ? 0.6f : 0.25f, min(a.balance[19], kBalanceSlots));
@@ -1950,7 +2026,7 @@ hipError_t launch_trace(const TraceArgs &args, const LaunchInfo &li, hipStream_t
         hipLaunchKernelGGL(trace_restart_kernel, dim3(blocks), dim3(256), 0, stream, args, (const uint32_t *)nullptr);
         return hipGetLastError();
     }
-    // li.counters = {8 claim counters (128 B apart), deferred-ray count, deferred items}: zero when a frame
+    // li.counters = {64 claim counters (kCounterStride words apart), deferred-ray count, deferred items}: zero when a frame
     // starts (armed at allocation and re-armed by the last kernel of the previous frame)
     const bool ge = (args.u.flags & SVO_F_MISC_BOOL) != 0;
     if (li.deep_stack)  // trees deeper than kTopLevels + 1 + kStackLevels: more LDS per workgroup, fewer resident waves

@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--res", default="1920x1080")
 ap.add_argument("--census", action="store_true")
+ap.add_argument("--only", type=int, default=-1, help="0 static, 1 cleared, 2 carried (for a counter pass of one mode)")
 a = ap.parse_args()
 pkg = entry.load_package()
 cam, look = pkg.scenes.terrain_camera(0, 16)
@@ -67,6 +68,6 @@ if "--census" in sys.argv:
     sys.exit(0)
 for name, clear, flags in (("static (counters paused)", False, dict(pause_adaptive=True, shadows=False)),
                            ("counters live, cleared before every frame", True, dict(pause_adaptive=False, shadows=False)),
-                           ("counters live, carried over", False, dict(pause_adaptive=False, shadows=False))):
+                           ("counters live, carried over", False, dict(pause_adaptive=False, shadows=False)))[slice(None) if a.only < 0 else slice(a.only, a.only + 1)]:
     med, best = run(clear, flags)
     print(f"{name}: median {med:.3f} ms, min {best:.3f} ms per {W}x{H} frame", flush=True)

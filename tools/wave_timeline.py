@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--raw", default=None, help="save the per-wave words (timeline, events) as .npz")
     ap.add_argument("--count", action="store_true", help="hit counters live, cleared before the frame (the reference's default mode)")
     ap.add_argument("--carry", action="store_true", help="with --count: the counters carry over from frame to frame (no scan in between)")
+    ap.add_argument("--frames", type=int, default=0, help="frames before the measured one (default: 24, with --carry 8)")
     ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE for gpu.set_option (e.g. REFILL_MIN=8)")
     a = ap.parse_args()
     pkg = entry.load_package()
@@ -70,7 +71,7 @@ def main():
     dbg = torch.zeros((2 * 16384, 16), dtype=torch.int32, device="cuda")  # second half: per-wave event stamps (round 5)
     hits = render.alloc_hits(W * H)
     gpu.set_option(pkg.gpu.OPT_TIMING, 8)
-    for _ in range(8 if a.carry else 24):
+    for _ in range(a.frames or (8 if a.carry else 24)):
         clear()
         render.render(hits=hits)
     ms_plain = gpu.last_render_ms()
@@ -79,6 +80,7 @@ def main():
     gpu.set_option(pkg.gpu.OPT_DEBUG_BUFFER, dbg.data_ptr())
     for _ in range(2):  # (the first launch of the timeline instantiation starts seven of the eight XCDs 100 us late: its scratch memory is set up then)
         dbg.zero_()
+        clear()  # (--count without --carry: every frame starts from cleared counters, the measured one too)
         if a.cold:
             gpu.set_option(pkg.gpu.OPT_SCHEDULE, 2)  # (setting the period forgets the schedule)
         render.render(hits=hits)
