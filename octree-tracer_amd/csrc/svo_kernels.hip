@@ -479,7 +479,10 @@ __global__ __launch_bounds__(BLOCK, NS > 12 ? 4 : (CNT ? SVO_WAVES_PER_SIMD_CNT 
         const uint32_t n = visit_groups<true>(a.n_words, p, mine ? word : 15u);
         const uint64_t m = __ballot(n != 0u);
         if (!m) return;
-        if (cq_n > (uint32_t)kCountQueue - 64u) {
+#ifndef SVO_COUNT_FLUSH_AT   // (A/B: flush once the queue holds more than this many records; at most kCountQueue - 64, a push adds up to 64)
+#define SVO_COUNT_FLUSH_AT (kCountQueue - 64)
+#endif
+        if (cq_n > (uint32_t)(SVO_COUNT_FLUSH_AT)) {
             if (DBGH) dbg_desc_rounds += 1u;  // (CNT: slot 14 = queue flushes, slot 13 = cycles in them)
             const uint64_t c_f0 = DBGH ? __builtin_amdgcn_s_memtime() : 0ull;
             cq_flush();
