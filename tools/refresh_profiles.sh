@@ -15,7 +15,9 @@ python3 tools/count_probe.py > "$OUT/count_probe.log" 2>&1; tail -3 "$OUT/count_
 python3 tools/shade_probe.py > "$OUT/shade_probe.log" 2>&1; tail -4 "$OUT/shade_probe.log"
 python3 tools/default_mode_probe.py > "$OUT/default_mode_probe.log" 2>&1
 python3 tools/default_mode_probe.py --carry >> "$OUT/default_mode_probe.log" 2>&1
-python3 tools/default_mode_probe.py --fused 1 >> "$OUT/default_mode_probe.log" 2>&1; tail -3 "$OUT/default_mode_probe.log"
+python3 tools/default_mode_probe.py --fused 1 >> "$OUT/default_mode_probe.log" 2>&1
+python3 tools/default_mode_probe.py --fused 0 >> "$OUT/default_mode_probe.log" 2>&1; tail -4 "$OUT/default_mode_probe.log"
+python3 tools/wave_timeline.py --json "$OUT/timeline_heavy_1080p.json" > /dev/null 2> "$OUT/timeline.err" || echo "timeline failed"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 /root/repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras > "$OUT/trace.json" 2> "$OUT/trace.err" || echo "kernel trace failed"
 find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
