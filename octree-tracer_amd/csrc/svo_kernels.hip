@@ -1598,20 +1598,37 @@ __global__ __launch_bounds__(256) void scan_kernel(uint32_t *nodes, uint32_t n_w
 // follow: share *= 1 + gain (mean / time - 1), clamped per step and in total.
 // (called by all 256 threads of one workgroup, only for frames that are fed back: every workgroup of a frame overwrites its stamp, so
 // nothing has to be cleared in between)
-__device__ __forceinline__ void balance_step(uint32_t *bal, float gain, uint32_t n_slots) {
+// The shares are a proposal, not a proof: on the depth-20 fractal at 4K the frame they converge to is a tenth SLOWER than the one with equal
+// shares (profiles/r05_balance_probe.log).  So the step also notes how long the frame took with the shares it was traced with (the latest
+// of the sampled end stamps), remembers the best shares seen since the layout was new -- the equal shares of its first frame included --
+// and the last of the 16 steps of a resting view puts those back: the schedule that is then kept is never worse than the unweighted one.
+__device__ __forceinline__ void balance_step(uint32_t *bal, float gain, uint32_t n_slots, uint32_t update) {
     __shared__ float t_sum[8], t_n[8];
+    __shared__ uint32_t t_last;
     const uint32_t t0 = bal[9];
     if (threadIdx.x < 8u) t_sum[threadIdx.x] = t_n[threadIdx.x] = 0.0f;
+    if (threadIdx.x == 0u) t_last = 0u;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_slots; i += 256u) {  // slot i: workgroup i, of list i % 8
         const float t = (float)(bal[kBalanceHead + i] - t0);  // (10 ns ticks; the difference survives a wrap of the counter)
         if (t > 0.0f && t < 1.0e8f) {
             atomicAdd(&t_sum[i & 7u], t);
             atomicAdd(&t_n[i & 7u], 1.0f);
+            atomicMax(&t_last, (uint32_t)t);
         }
     }
     __syncthreads();
     if (threadIdx.x != 0u) return;
+    // [20] the shortest frame so far (ticks; 0: none yet), [21..29] the shares it was traced with
+    if (update <= 16u && t_last != 0u && (update == 1u || bal[20] == 0u || t_last < bal[20])) {
+        bal[20] = t_last;
+        for (int k = 0; k <= 8; k++) bal[21 + k] = bal[k];
+    }
+    if (update == 16u && bal[20] != 0u) {  // the schedule built next is the one a resting view keeps
+        for (int k = 0; k <= 8; k++) bal[k] = bal[21 + k];
+        bal[18] += 1u;
+        return;
+    }
     float T[8], w[8], mean = 0.0f;
     bool ok = true;
     for (int k = 0; k < 8; k++) {
@@ -1648,7 +1665,7 @@ __global__ __launch_bounds__(256) void post_kernel(TraceArgs a, uint32_t *claim_
         for (uint32_t i = threadIdx.x; i < 64u; i += 256u) claim_counters[i * (uint32_t)kCounterStride] = 0u;
         if (threadIdx.x == 0) *next_deferred_count = 0u;
         // (balance_update: n > 0 = the n-th frame fed back: the first steps are large, the later ones small)
-        if (a.balance != nullptr && balance_update != 0u) balance_step(a.balance, balance_update <= 6u ? 0.6f : 0.25f, min(a.balance[19], kBalanceSlots));
+        if (a.balance != nullptr && balance_update != 0u) balance_step(a.balance, balance_update <= 6u ? 0.6f : 0.25f, min(a.balance[19], kBalanceSlots), balance_update);
     }
     const uint32_t n_def = list[0];
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_def; i += gridDim.x * 256u) {
