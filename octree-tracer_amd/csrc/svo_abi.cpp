@@ -268,12 +268,15 @@ int trace_launch(svo_ctx *ctx, const svo::WorkDesc &work, const float *rays, svo
         const bool fed_back = a.balance != nullptr && a.order != nullptr && !filtered;
         const bool rebuild = schedule && (!sc.valid || (sc.order_filtered && !filtered) || (!same_input && sc.age + 1 >= ctx->sched_period) ||
                                           (same_input && sc.floored && !moving) || (same_input && fed_back && sc.balance_frames < 16u));
+        // (a resting view rebuilt for the shares' sake only: its strips' cost classes are the ones measured last time, the pass is skipped)
+        const bool shares_only = rebuild && sc.valid && same_input && fed_back && sc.balance_frames < 16u && !(sc.order_filtered && !filtered) &&
+                                 !(sc.floored && !moving);
         // a camera in motion: strips near the long ones of this frame are not scheduled as cheap (strip_danger_kernel)
         const bool floor_now = rebuild && !filtered && moving && ctx->motion_floor != 0u && wd.mode == 0 && wd.n_rects == 1u;
         // (a launch with a skip mask builds its lists before the trace, every frame: here only the costs are measured)
         HIP_TRY(ctx, svo::launch_post(a, li, rebuild ? sc.cost : nullptr, sc.order, n_strips, svo::order_list_cap(wd, n_strips),
                                       rebuild && !filtered, ctx->stream, floor_now ? sc.cls_now : nullptr, ctx->motion_floor,
-                                      (fed_back && (!same_input || sc.balance_frames < 16u)) ? sc.balance_frames + 1u : 0u));
+                                      (fed_back && (!same_input || sc.balance_frames < 16u)) ? sc.balance_frames + 1u : 0u, shares_only));
         if (fed_back) sc.balance_frames++;
         if (rebuild && !filtered) sc.floored = floor_now;
         sc.prev_uniforms = ctx->uniforms;

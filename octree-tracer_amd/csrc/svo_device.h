@@ -105,7 +105,7 @@ constexpr uint32_t kBalanceHead = 32, kBalanceSlots = 4096, kBalanceWords = kBal
 inline uint32_t order_list_cap(const WorkDesc &, uint32_t n_strips) { return (n_strips + 3u) / 4u + kCostClasses; }
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
                        uint32_t cap, bool build_schedule, hipStream_t stream, uint8_t *moved = nullptr, uint32_t motion_floor = 0,
-                       uint32_t balance_update = 0);
+                       uint32_t balance_update = 0, bool reuse_cost = false);
 
 // explicit rays with a skip mask: this frame's strip lists without the strips that hold no ray (classes from `prev`, or screen order)
 hipError_t launch_schedule_skipping(const uint8_t *skip, uint32_t n_items, const uint8_t *prev, uint8_t *cls, uint32_t *sched,

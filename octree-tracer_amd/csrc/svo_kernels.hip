@@ -2231,14 +2231,17 @@ __global__ __launch_bounds__(256) void strip_danger_kernel(const uint8_t *in, ui
 }
 
 hipError_t launch_post(const TraceArgs &args, const LaunchInfo &li, uint8_t *cost, uint32_t *sched, uint32_t n_strips,
-                       uint32_t cap, bool build_schedule, hipStream_t stream, uint8_t *moved, uint32_t motion_floor, uint32_t balance_update) {
+                       uint32_t cap, bool build_schedule, hipStream_t stream, uint8_t *moved, uint32_t motion_floor, uint32_t balance_update,
+                       bool reuse_cost) {
     // without the cost pass the launch only re-arms counters and traces deferred rays: normally none, but a frame
     // full of them (every ray NaN / extreme) must not crawl through 16 workgroups
-    uint32_t blocks = cost ? (n_strips + 3u) / 4u : 256u;
+    // (reuse_cost: the classes in `cost` are this input's already -- a resting view whose lists are rebuilt for the shares' sake only)
+    uint8_t *const measure = reuse_cost ? nullptr : cost;
+    uint32_t blocks = measure ? (n_strips + 3u) / 4u : 256u;
     if (blocks > 2048u) blocks = 2048u;
     if (blocks < 16u) blocks = 16u;
     hipLaunchKernelGGL(post_kernel, dim3(blocks), dim3(256), 0, stream, args, li.counters, (const uint32_t *)li.defer,
-                       li.next_defer_count, cost, n_strips, balance_update);
+                       li.next_defer_count, measure, n_strips, balance_update);
     if (cost && build_schedule) {
         const uint8_t *cls = cost;
         if (moved && motion_floor) {  // (pixel frames of one rectangle: the ABI passes `moved` only then)
