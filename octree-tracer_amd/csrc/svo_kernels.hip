@@ -35,7 +35,7 @@
 #define SVO_WALK_ASM 1  // instruction on the execute mask and the branch
 #endif
 #ifndef SVO_WALK_LUT   // 1: the walk takes the child indices of six levels at a time from one register built with three LDS look-ups (a 64-entry
-#define SVO_WALK_LUT 2  // bit-spreading table) instead of three bit-field extracts and two shift-ors per level (default kernel, static tree)
+#define SVO_WALK_LUT 2  // bit-spreading table) instead of three bit-field extracts and two shift-ors per level (trees up to depth 16; the counting kernels too: SVO_WALK_LUT_CNT)
 #endif
 #ifndef SVO_WALK_LUT_CNT   // the same walk in the counting instantiations (hit counters live), the saturation notes as one carry bit per level
 #define SVO_WALK_LUT_CNT 1
